@@ -1,0 +1,137 @@
+"""ctypes binding of the C ABI in include/calciumgan_hip.h.
+
+The HIP library is the ONLY compute path of this package: if it is missing or
+fails to load, every op raises (there is no CPU / eager fallback).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libcalciumgan_hip.so')
+
+CG_EINVAL = 100001
+EPI_NONE, EPI_LRELU, EPI_MASK, EPI_SIGMOID = 0, 1, 2, 3
+
+c_vp = C.c_void_p
+c_i = C.c_int
+c_ll = C.c_longlong
+c_f = C.c_float
+
+
+class ConvDesc(C.Structure):
+  """struct cg_conv_desc."""
+  _fields_ = [
+      ('x', c_vp), ('w', c_vp), ('y', c_vp), ('bias', c_vp), ('mask_src', c_vp),
+      ('shifts', c_vp),
+      ('nB', c_i), ('Lx', c_i), ('Cx', c_i), ('seg_size', c_i),
+      ('taps', c_i), ('stride', c_i), ('off', c_i), ('Lu', c_i),
+      ('N', c_i), ('Ly', c_i), ('Cy', c_i), ('y_stride', c_i), ('y_off', c_i),
+      ('CK', c_i),
+      ('epilogue', c_i), ('out_f32', c_i),
+      ('alpha', c_f),
+      ('nphase', c_i),
+      ('w_phase_stride', c_ll),
+      ('off_phase_step', c_i), ('yoff_phase_step', c_i),
+      ('small_tile', c_i),
+  ]
+
+
+class PackDesc(C.Structure):
+  """struct cg_pack_desc."""
+  _fields_ = [
+      ('src', c_vp), ('dst', c_vp),
+      ('taps', c_i), ('tap0', c_i), ('tap_step', c_i),
+      ('s_tap', c_ll), ('s_c', c_ll), ('s_n', c_ll),
+      ('C_real', c_i), ('N_real', c_i), ('Cx', c_i), ('CK', c_i),
+  ]
+
+
+class WgradDesc(C.Structure):
+  """struct cg_wgrad_desc."""
+  _fields_ = [
+      ('x', c_vp), ('g', c_vp), ('dw', c_vp), ('shifts', c_vp),
+      ('nB', c_i), ('Lx', c_i), ('Cx', c_i), ('seg_size', c_i),
+      ('Lu', c_i), ('Cg', c_i),
+      ('taps', c_i), ('stride', c_i), ('off', c_i),
+      ('Cx_real', c_i), ('Cg_real', c_i),
+      ('nsplit', c_i),
+  ]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    'cg_abi_version': [],
+    'cg_swconv': [C.POINTER(ConvDesc), c_vp],
+    'cg_packed_elems': [c_i, c_i, c_i, c_i],
+    'cg_pack_weights': [C.POINTER(PackDesc), c_vp],
+    'cg_wgrad': [C.POINTER(WgradDesc), c_vp],
+    'cg_ln_lrelu_fwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_f,
+                        c_f, c_vp],
+    'cg_ln_lrelu_bwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                        c_ll, c_i, c_i, c_f, c_vp],
+    'cg_dense1_fwd': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    'cg_dense1_bwd': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f,
+                      c_vp],
+    'cg_dense1_wgrad': [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i,
+                        c_vp],
+    'cg_unshuffle_mask': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f,
+                          c_vp],
+    'cg_interp_pack': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i,
+                       c_vp],
+    'cg_cast_pad': [c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],
+    'cg_rownorm': [c_vp, c_vp, c_i, c_ll, c_vp],
+    'cg_gp_finalize': [c_vp, c_vp, c_vp, c_i, c_f, c_vp],
+    'cg_scale_rows': [c_vp, c_vp, c_vp, c_i, c_ll, c_vp],
+    'cg_critic_loss': [c_vp, c_vp, c_f, c_vp, c_i, c_vp],
+    'cg_neg_mean': [c_vp, c_vp, c_i, c_vp],
+    'cg_colsum': [c_vp, c_vp, c_ll, c_i, c_i, c_vp],
+    'cg_sigmoid_bwd': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],
+    'cg_lrelu_bwd': [c_vp, c_vp, c_vp, c_ll, c_f, c_vp],
+    'cg_adam': [c_vp, c_vp, c_vp, c_vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_vp],
+    'cg_signal_metrics': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_f, c_f,
+                          c_vp],
+}
+_RESTYPES = {'cg_packed_elems': c_ll}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+  pass
+
+
+def load():
+  """Load (once) and return the ctypes handle.  Raises HipLibraryError when the
+  library has not been built -- there is deliberately no fallback path."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise HipLibraryError(
+        'calciumgan_amd: {} not found. Build it with `python -m '
+        'calciumgan_amd.build` (hipcc --offload-arch=gfx950); there is no '
+        'CPU fallback.'.format(LIB_PATH))
+  try:
+    lib = C.CDLL(LIB_PATH)
+  except OSError as e:
+    raise HipLibraryError('calciumgan_amd: cannot load {}: {}'.format(
+        LIB_PATH, e))
+  for name, argtypes in SIGNATURES.items():
+    fn = getattr(lib, name)  # AttributeError if the symbol is missing
+    fn.argtypes = argtypes
+    fn.restype = _RESTYPES.get(name, c_i)
+  _lib = lib
+  return lib
+
+
+def check(rc, what):
+  if rc != 0:
+    if rc == CG_EINVAL:
+      raise ValueError('{}: unsupported shape/arguments (CG_EINVAL)'.format(what))
+    raise RuntimeError('{}: HIP error {}'.format(what, rc))
+
+
+def call(name, *args):
+  """Invoke an int-returning entry point and raise on a non-zero code."""
+  rc = getattr(load(), name)(*args)
+  check(rc, name)

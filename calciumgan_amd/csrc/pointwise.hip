@@ -1,0 +1,743 @@
+// HBM-bound kernels of the CalciumGAN hot path: LayerNorm(+LeakyReLU),
+// discriminator head, phase-unshuffle, WGAN-GP interpolation / penalty norm,
+// bias gradients, Keras Adam, signal metrics.  All loads/stores are 16-byte
+// (8 x bf16 or 4 x f32) per lane and row-contiguous; reductions use wavefront
+// shuffles (64 lanes) then one atomic per wave/block.
+#include "cg_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline unsigned grid1d(long long work, int per_block, long long cap = 1 << 20) {
+  long long b = (work + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+__device__ __forceinline__ void load8(const uint16_t* p, float* v) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(w[i] << 16);
+    v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void store8(uint16_t* p, const float* v) {
+  *reinterpret_cast<uint4*>(p) =
+      make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]),
+                 pack2bf(v[6], v[7]));
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm + LeakyReLU.  One wave per row; Cp <= 512 -> one 8-channel group
+// per lane.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void ln_fwd_kernel(
+    const uint16_t* __restrict__ y, const float* __restrict__ gamma,
+    const float* __restrict__ beta, uint16_t* __restrict__ h,
+    float* __restrict__ mean_o, float* __restrict__ rstd_o, long long rows,
+    int C, int Cp, float eps, float alpha) {
+  const int lane = threadIdx.x & 63;
+  const long long row =
+      (long long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c0 = lane * 8;
+  float v[8];
+  const bool active = c0 < Cp;
+  if (active) load8(y + row * Cp + c0, v);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (active && c0 + e < C) s += v[e];
+  const float mean = wave_sum(s) / C;
+  float s2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (active && c0 + e < C) {
+      const float d = v[e] - mean;
+      s2 += d * d;
+    }
+  const float rstd = rsqrtf(wave_sum(s2) / C + eps);
+  if (lane == 0) {
+    if (mean_o) mean_o[row] = mean;
+    if (rstd_o) rstd_o[row] = rstd;
+  }
+  if (active) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+      if (c0 + e < C) {
+        t = (v[e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
+        t = t > 0.f ? t : alpha * t;
+      }
+      o[e] = t;
+    }
+    store8(h + row * Cp + c0, o);
+  }
+}
+
+// dy = rstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)), dyh = do * gamma,
+// do = dh * lrelu'(h); dgamma += do * xhat, dbeta += do (per-block partials in
+// LDS, then one atomic per channel per block).
+__global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
+    const uint16_t* __restrict__ dh, const uint16_t* __restrict__ h,
+    const uint16_t* __restrict__ y, const float* __restrict__ mean_i,
+    const float* __restrict__ rstd_i, const float* __restrict__ gamma,
+    uint16_t* __restrict__ dy, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, long long rows, int C, int Cp, float alpha,
+    int rows_per_wave) {
+  __shared__ float sg[4][512];
+  __shared__ float sb[4][512];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int c0 = lane * 8;
+  const bool active = c0 < Cp;
+  float gam[8], accg[8], accb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    gam[e] = (active && c0 + e < C) ? gamma[c0 + e] : 0.f;
+    accg[e] = 0.f;
+    accb[e] = 0.f;
+  }
+  const long long wave_id = (long long)blockIdx.x * 4 + wave;
+  const long long r0 = wave_id * rows_per_wave;
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
+    const long long row = r0 + rr;
+    if (row >= rows) break;
+    float vd[8], vh[8], vy[8];
+    if (active) {
+      load8(dh + row * Cp + c0, vd);
+      load8(h + row * Cp + c0, vh);
+      load8(y + row * Cp + c0, vy);
+    }
+    const float mean = mean_i[row];
+    const float rstd = rstd_i[row];
+    float xh[8], dyh[8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      xh[e] = 0.f;
+      dyh[e] = 0.f;
+      if (active && c0 + e < C) {
+        const float d_o = vd[e] * (vh[e] > 0.f ? 1.f : alpha);
+        xh[e] = (vy[e] - mean) * rstd;
+        dyh[e] = d_o * gam[e];
+        accg[e] += d_o * xh[e];
+        accb[e] += d_o;
+        s1 += dyh[e];
+        s2 += dyh[e] * xh[e];
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+    if (active) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o[e] = (c0 + e < C) ? rstd * (dyh[e] - s1 - xh[e] * s2) : 0.f;
+      store8(dy + row * Cp + c0, o);
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sg[wave][c0 + e] = accg[e];
+      sb[wave][c0 + e] = accb[e];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += kThreads) {
+    atomicAdd(dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+    atomicAdd(dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// discriminator head
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void dense1_fwd_kernel(
+    const uint16_t* __restrict__ h, const float* __restrict__ w,
+    const float* __restrict__ bias, float* __restrict__ out, int F, int C,
+    int Cp) {
+  __shared__ float part[4];
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x * 8; i < F; i += kThreads * 8) {
+    float v[8];
+    load8(h + (long long)b * F + i, v);
+    const int t = i / Cp;
+    const int c = i - t * Cp;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (c + e < C) s += v[e] * bf2f(f2bf(w[t * C + c + e]));
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[b] = part[0] + part[1] + part[2] + part[3] + bias[0];
+}
+
+__global__ __launch_bounds__(kThreads) void dense1_bwd_kernel(
+    const float* __restrict__ w, const float* __restrict__ coef,
+    const uint16_t* __restrict__ h, uint16_t* __restrict__ delta, int F, int C,
+    int Cp, int seg_size, float alpha, long long total8) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
+  const int per_row = F / 8;
+  const int b = (int)(idx / per_row);
+  const int i = (int)(idx - (long long)b * per_row) * 8;
+  const float c = coef[b / seg_size];
+  float vh[8], o[8];
+  load8(h + (long long)b * F + i, vh);
+  const int t = i / Cp;
+  const int ch = i - t * Cp;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    o[e] = (ch + e < C) ? c * bf2f(f2bf(w[t * C + ch + e])) *
+                              (vh[e] > 0.f ? 1.f : alpha)
+                        : 0.f;
+  store8(delta + (long long)b * F + i, o);
+}
+
+// dw[i] += sum_b coef[seg(b)] * x[b][i]; grid (F/8/256, bsplit)
+__global__ __launch_bounds__(kThreads) void dense1_wgrad_kernel(
+    const uint16_t* __restrict__ x, const float* __restrict__ coef,
+    const float* __restrict__ bias_coef, float* __restrict__ dw,
+    float* __restrict__ db, int nB, int F, int C, int Cp, int seg_size) {
+  const int i = (blockIdx.x * kThreads + threadIdx.x) * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float bsum = 0.f;
+  for (int b = blockIdx.y; b < nB; b += gridDim.y) {
+    const float c = coef[b / seg_size];
+    if (i == 0 && bias_coef) bsum += bias_coef[b / seg_size];
+    if (i < F) {
+      float v[8];
+      load8(x + (long long)b * F + i, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += c * v[e];
+    }
+  }
+  if (i < F) {
+    const int t = i / Cp;
+    const int ch = i - t * Cp;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (ch + e < C) atomicAdd(dw + t * C + ch + e, acc[e]);
+  }
+  if (i == 0 && db && bias_coef) atomicAdd(db, bsum);
+}
+
+// ---------------------------------------------------------------------------
+// phase unshuffle + LeakyReLU mask
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void unshuffle_mask_kernel(
+    const uint16_t* __restrict__ e, const uint16_t* __restrict__ h,
+    uint16_t* __restrict__ delta, const int* __restrict__ shifts, int w, int Cp,
+    int seg_size, float alpha, long long total8) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
+  const int per_row = Cp / 8;
+  const long long rowg = idx / per_row;
+  const int c = (int)(idx - rowg * per_row) * 8;
+  const int b = (int)(rowg / w);
+  const int r = (int)(rowg - (long long)b * w);
+  const int s = shifts ? shifts[b / seg_size] : 0;
+  // all t with shuffle_src(t, s, w) == r
+  int t0, t1 = -1;
+  if (s > 0) {
+    t0 = r - s;                    // direct branch, valid if t0 >= 0
+    const int tr = 2 * (w - 1) - s - r;  // reflected branch, t in [w-s, w-1]
+    if (tr >= w - s && tr <= w - 1) t1 = tr;
+  } else {
+    const int a = -s;
+    t0 = r + a;                    // direct branch t >= a, valid if t0 < w
+    if (t0 >= w) t0 = -1;
+    const int tr = a - r;          // reflected branch t in [0, a)
+    if (tr >= 0 && tr < a) t1 = tr;
+  }
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float v[8];
+  const long long base = (long long)b * w;
+  if (t0 >= 0) {
+    load8(e + (base + t0) * Cp + c, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+  }
+  if (t1 >= 0) {
+    load8(e + (base + t1) * Cp + c, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+  }
+  load8(h + rowg * Cp + c, v);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] *= (v[k] > 0.f ? 1.f : alpha);
+  store8(delta + rowg * Cp + c, acc);
+}
+
+// ---------------------------------------------------------------------------
+// WGAN-GP pieces
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void interp_pack_kernel(
+    const float* __restrict__ real, const float* __restrict__ fake,
+    const float* __restrict__ alpha, uint16_t* __restrict__ x0, int B, int L,
+    int C, int Cr, int Cf, int Cp, long long total8) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
+  const int per_row = Cp / 8;
+  const long long row = idx / per_row;  // b*L + t
+  const int c = (int)(idx - row * per_row) * 8;
+  const int b = (int)(row / L);
+  const float al = alpha[b];
+  float r[8], f[8], x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool ok = c + e < C;
+    r[e] = ok ? real[row * Cr + c + e] : 0.f;
+    f[e] = ok ? fake[row * Cf + c + e] : 0.f;
+    x[e] = al * r[e] + (1.f - al) * f[e];
+  }
+  const long long seg = (long long)B * L * Cp;
+  store8(x0 + row * Cp + c, r);
+  store8(x0 + seg + row * Cp + c, f);
+  store8(x0 + 2 * seg + row * Cp + c, x);
+}
+
+__global__ __launch_bounds__(kThreads) void cast_pad_kernel(
+    const float* __restrict__ src, uint16_t* __restrict__ dst, int C, int Cs,
+    int Cp, long long total8) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
+  const int per_row = Cp / 8;
+  const long long row = idx / per_row;
+  const int c = (int)(idx - row * per_row) * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (c + e < C) ? src[row * Cs + c + e] : 0.f;
+  store8(dst + row * Cp + c, v);
+}
+
+// sumsq[b] += partial; grid (chunks, B)
+__global__ __launch_bounds__(kThreads) void sumsq_kernel(
+    const float* __restrict__ g, float* __restrict__ sumsq, long long n) {
+  __shared__ float part[4];
+  const int b = blockIdx.y;
+  const float* p = g + (long long)b * n;
+  float s = 0.f;
+  for (long long i = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4; i < n;
+       i += (long long)gridDim.x * kThreads * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicAdd(sumsq + b, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ void sqrt_kernel(float* v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = sqrtf(v[i]);
+}
+
+__global__ void gp_finalize_kernel(const float* __restrict__ norm,
+                                   float* __restrict__ gp,
+                                   float* __restrict__ coef, int B,
+                                   float scale) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += kThreads) {
+    const float nv = norm[b];
+    const float d = nv - 1.f;
+    s += d * d;
+    coef[b] = scale * 2.f * d / (B * nv);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) gp[0] = (part[0] + part[1] + part[2] + part[3]) / B;
+}
+
+__global__ __launch_bounds__(kThreads) void scale_rows_kernel(
+    const float* __restrict__ g, const float* __restrict__ coef,
+    uint16_t* __restrict__ a0, long long n, long long total8) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
+  const long long i = idx * 8;
+  const int b = (int)(i / n);
+  const float c = coef[b];
+  const f32x4 v0 = *reinterpret_cast<const f32x4*>(g + i);
+  const f32x4 v1 = *reinterpret_cast<const f32x4*>(g + i + 4);
+  const float o[8] = {c * v0[0], c * v0[1], c * v0[2], c * v0[3],
+                      c * v1[0], c * v1[1], c * v1[2], c * v1[3]};
+  store8(a0 + i, o);
+}
+
+__global__ void critic_loss_kernel(const float* __restrict__ d_out,
+                                   const float* __restrict__ gp, float penalty,
+                                   float* __restrict__ out, int B) {
+  __shared__ float pr[4], pf[4];
+  float sr = 0.f, sf = 0.f;
+  for (int b = threadIdx.x; b < B; b += kThreads) {
+    sr += d_out[b];
+    sf += d_out[B + b];
+  }
+  sr = wave_sum(sr);
+  sf = wave_sum(sf);
+  if ((threadIdx.x & 63) == 0) {
+    pr[threadIdx.x >> 6] = sr;
+    pf[threadIdx.x >> 6] = sf;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float mr = (pr[0] + pr[1] + pr[2] + pr[3]) / B;
+    const float mf = (pf[0] + pf[1] + pf[2] + pf[3]) / B;
+    out[0] = -mr + mf + penalty * gp[0];
+    out[1] = -mf;
+  }
+}
+
+__global__ void neg_mean_kernel(const float* __restrict__ d_out,
+                                float* __restrict__ out, int B) {
+  __shared__ float pr[4];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += kThreads) s += d_out[b];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) pr[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = -(pr[0] + pr[1] + pr[2] + pr[3]) / B;
+}
+
+// column sums: block handles `rows_per_block` rows; thread -> (8-channel group,
+// row lane); LDS reduce then one atomic per channel per block.
+__global__ __launch_bounds__(kThreads) void colsum_kernel(
+    const uint16_t* __restrict__ x, float* __restrict__ out, long long rows,
+    int C, int Cp, int rows_per_block) {
+  extern __shared__ float sacc[];  // [Cp]
+  const int groups = Cp / 8;
+  const int rlanes = kThreads / groups;  // rows processed concurrently
+  for (int c = threadIdx.x; c < Cp; c += kThreads) sacc[c] = 0.f;
+  __syncthreads();
+  const int grp = threadIdx.x % groups;
+  const int rl = threadIdx.x / groups;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < rlanes) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    for (int rr = rl; rr < rows_per_block; rr += rlanes) {
+      const long long row = r0 + rr;
+      if (row >= rows) break;
+      float v[8];
+      load8(x + row * Cp + grp * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&sacc[grp * 8 + e], acc[e]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += kThreads) atomicAdd(out + c, sacc[c]);
+}
+
+__global__ __launch_bounds__(kThreads) void sigmoid_bwd_kernel(
+    const float* __restrict__ dfake, const float* __restrict__ fake,
+    uint16_t* __restrict__ dz, int C, int Cf, int Cp, long long total8) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
+  const int per_row = Cp / 8;
+  const long long row = idx / per_row;
+  const int c = (int)(idx - row * per_row) * 8;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float t = 0.f;
+    if (c + e < C) {
+      const float s = fake[row * Cf + c + e];
+      t = dfake[row * Cp + c + e] * s * (1.f - s);
+    }
+    o[e] = t;
+  }
+  store8(dz + row * Cp + c, o);
+}
+
+__global__ __launch_bounds__(kThreads) void lrelu_bwd_kernel(
+    const uint16_t* __restrict__ dh, const uint16_t* __restrict__ h,
+    uint16_t* __restrict__ dpre, float alpha, long long total8) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
+  float a[8], b[8];
+  load8(dh + idx * 8, a);
+  load8(h + idx * 8, b);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] *= (b[e] > 0.f ? 1.f : alpha);
+  store8(dpre + idx * 8, a);
+}
+
+__global__ __launch_bounds__(kThreads) void adam_kernel(
+    float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
+    float* __restrict__ v, long long n, float lr_t, float b1, float b2,
+    float eps, float gscale) {
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const float g = grad[i] * gscale;
+  const float mi = b1 * m[i] + (1.f - b1) * g;
+  const float vi = b2 * v[i] + (1.f - b2) * g * g;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
+// one wave per row (b,t): min/max/mean/std over channels of real and fake
+__global__ __launch_bounds__(kThreads) void signal_metrics_kernel(
+    const float* __restrict__ real, const float* __restrict__ fake,
+    float* __restrict__ out, long long rows, int C, int Cr, int Cf, float smin,
+    float scale, int rows_per_wave) {
+  __shared__ float part[4][4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float acc[4] = {0, 0, 0, 0};
+  const long long r0 = ((long long)blockIdx.x * 4 + wave) * rows_per_wave;
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
+    const long long row = r0 + rr;
+    if (row >= rows) break;
+    float st[2][4];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const float* p = which ? fake + row * Cf : real + row * Cr;
+      float mn = INFINITY, mx = -INFINITY, s = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float v = p[c] * scale + smin;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+        s += v;
+      }
+      mn = wave_min(mn);
+      mx = wave_max(mx);
+      const float mean = wave_sum(s) / C;
+      float s2 = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float d = p[c] * scale + smin - mean;
+        s2 += d * d;
+      }
+      st[which][0] = mn;
+      st[which][1] = mx;
+      st[which][2] = mean;
+      st[which][3] = sqrtf(wave_sum(s2) / C);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float d = st[0][k] - st[1][k];
+      acc[k] += d * d;
+    }
+  }
+  if (lane == 0)
+    for (int k = 0; k < 4; ++k) part[wave][k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 4)
+    atomicAdd(out + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] +
+                                     part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+}  // namespace
+
+#define S_(x) ((hipStream_t)(x))
+#define U16(x) (reinterpret_cast<const uint16_t*>(x))
+#define U16W(x) (reinterpret_cast<uint16_t*>(x))
+
+extern "C" int cg_ln_lrelu_fwd(const void* y_pre, const float* gamma,
+                               const float* beta, void* h, float* mean,
+                               float* rstd, long long rows, int C, int Cp,
+                               float eps, float alpha, void* stream) {
+  if (Cp % 8 || Cp > 512 || C > Cp || rows < 1) return CG_EINVAL;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid1d(rows, 4, 1LL << 31)),
+                     dim3(kThreads), 0, S_(stream), U16(y_pre), gamma, beta,
+                     U16W(h), mean, rstd, rows, C, Cp, eps, alpha);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_ln_lrelu_bwd(const void* dh, const void* h, const void* y_pre,
+                               const float* mean, const float* rstd,
+                               const float* gamma, void* dy, float* dgamma,
+                               float* dbeta, long long rows, int C, int Cp,
+                               float alpha, void* stream) {
+  if (Cp % 8 || Cp > 512 || C > Cp || rows < 1) return CG_EINVAL;
+  const int rows_per_wave = 32;
+  hipLaunchKernelGGL(ln_bwd_kernel,
+                     dim3(grid1d(rows, 4 * rows_per_wave, 1LL << 31)),
+                     dim3(kThreads), 0, S_(stream), U16(dh), U16(h), U16(y_pre),
+                     mean, rstd, gamma, U16W(dy), dgamma, dbeta, rows, C, Cp,
+                     alpha, rows_per_wave);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_dense1_fwd(const void* h, const float* w, const float* bias,
+                             float* out, int nB, int Lt, int C, int Cp,
+                             void* stream) {
+  const int F = Lt * Cp;
+  if (Cp % 8 || C > Cp || nB < 1) return CG_EINVAL;
+  hipLaunchKernelGGL(dense1_fwd_kernel, dim3(nB), dim3(kThreads), 0, S_(stream),
+                     U16(h), w, bias, out, F, C, Cp);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_dense1_bwd(const float* w, const float* coef, const void* h,
+                             void* delta, int nB, int Lt, int C, int Cp,
+                             int seg_size, float alpha, void* stream) {
+  const int F = Lt * Cp;
+  if (Cp % 8 || C > Cp || nB < 1 || seg_size < 1) return CG_EINVAL;
+  const long long total8 = (long long)nB * F / 8;
+  hipLaunchKernelGGL(dense1_bwd_kernel, dim3(grid1d(total8, kThreads, 1LL << 31)),
+                     dim3(kThreads), 0, S_(stream), w, coef, U16(h),
+                     U16W(delta), F, C, Cp, seg_size, alpha, total8);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_dense1_wgrad(const void* x, const float* coef,
+                               const float* bias_coef, float* dw, float* db,
+                               int nB, int Lt, int C, int Cp, int seg_size,
+                               void* stream) {
+  const int F = Lt * Cp;
+  if (Cp % 8 || C > Cp || nB < 1 || seg_size < 1) return CG_EINVAL;
+  const int gx = (F / 8 + kThreads - 1) / kThreads;
+  int gy = 512 / gx;
+  if (gy < 1) gy = 1;
+  if (gy > nB) gy = nB;
+  hipLaunchKernelGGL(dense1_wgrad_kernel, dim3(gx, gy), dim3(kThreads), 0,
+                     S_(stream), U16(x), coef, bias_coef, dw, db, nB, F, C,
+                     Cp, seg_size);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_unshuffle_mask(const void* e, const void* h, void* delta,
+                                 const int* shifts, int nB, int w, int Cp,
+                                 int seg_size, float alpha, void* stream) {
+  if (Cp % 8 || nB < 1 || w < 1 || seg_size < 1) return CG_EINVAL;
+  const long long total8 = (long long)nB * w * Cp / 8;
+  hipLaunchKernelGGL(unshuffle_mask_kernel,
+                     dim3(grid1d(total8, kThreads, 1LL << 31)), dim3(kThreads),
+                     0, S_(stream), U16(e), U16(h), U16W(delta), shifts, w, Cp,
+                     seg_size, alpha, total8);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_interp_pack(const float* real, const float* fake,
+                              const float* alpha, void* x0, int B, int L, int C,
+                              int Cr, int Cf, int Cp, void* stream) {
+  if (Cp % 8 || C > Cp || C > Cr || C > Cf) return CG_EINVAL;
+  const long long total8 = (long long)B * L * Cp / 8;
+  hipLaunchKernelGGL(interp_pack_kernel,
+                     dim3(grid1d(total8, kThreads, 1LL << 31)), dim3(kThreads),
+                     0, S_(stream), real, fake, alpha, U16W(x0), B, L, C, Cr,
+                     Cf, Cp, total8);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_cast_pad(const float* src, void* dst, long long rows, int C,
+                           int Cs, int Cp, void* stream) {
+  if (Cp % 8 || C > Cp || C > Cs) return CG_EINVAL;
+  const long long total8 = rows * Cp / 8;
+  hipLaunchKernelGGL(cast_pad_kernel, dim3(grid1d(total8, kThreads, 1LL << 31)),
+                     dim3(kThreads), 0, S_(stream), src, U16W(dst), C, Cs, Cp,
+                     total8);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_rownorm(const float* g, float* norm, int B, long long n,
+                          void* stream) {
+  if (n % 4 || B < 1) return CG_EINVAL;
+  hipError_t e = hipMemsetAsync(norm, 0, sizeof(float) * B, S_(stream));
+  if (e != hipSuccess) return (int)e;
+  int chunks = (int)((n / 4 + kThreads - 1) / kThreads);
+  if (chunks > 64) chunks = 64;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(chunks, B), dim3(kThreads), 0,
+                     S_(stream), g, norm, n);
+  hipLaunchKernelGGL(sqrt_kernel, dim3((B + 255) / 256), dim3(256), 0,
+                     S_(stream), norm, B);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_gp_finalize(const float* norm, float* gp, float* coef, int B,
+                              float scale, void* stream) {
+  hipLaunchKernelGGL(gp_finalize_kernel, dim3(1), dim3(kThreads), 0, S_(stream),
+                     norm, gp, coef, B, scale);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_scale_rows(const float* g, const float* coef, void* a0, int B,
+                             long long n, void* stream) {
+  if (n % 8) return CG_EINVAL;
+  const long long total8 = (long long)B * n / 8;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(grid1d(total8, kThreads, 1LL << 31)),
+                     dim3(kThreads), 0, S_(stream), g, coef, U16W(a0), n,
+                     total8);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_critic_loss(const float* d_out, const float* gp, float penalty,
+                              float* out, int B, void* stream) {
+  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(kThreads), 0, S_(stream),
+                     d_out, gp, penalty, out, B);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_neg_mean(const float* d_out, float* out, int B, void* stream) {
+  hipLaunchKernelGGL(neg_mean_kernel, dim3(1), dim3(kThreads), 0, S_(stream),
+                     d_out, out, B);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_colsum(const void* x, float* out, long long rows, int C,
+                         int Cp, void* stream) {
+  if (Cp % 8 || Cp / 8 > kThreads || C > Cp) return CG_EINVAL;
+  const int rows_per_block = 256;
+  hipLaunchKernelGGL(colsum_kernel,
+                     dim3(grid1d(rows, rows_per_block, 1LL << 31)),
+                     dim3(kThreads), Cp * sizeof(float), S_(stream), U16(x), out,
+                     rows, C, Cp, rows_per_block);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_sigmoid_bwd(const float* dfake, const float* fake, void* dz,
+                              long long rows, int C, int Cf, int Cp,
+                              void* stream) {
+  if (Cp % 8 || C > Cp || C > Cf) return CG_EINVAL;
+  const long long total8 = rows * Cp / 8;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel,
+                     dim3(grid1d(total8, kThreads, 1LL << 31)), dim3(kThreads),
+                     0, S_(stream), dfake, fake, U16W(dz), C, Cf, Cp, total8);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_lrelu_bwd(const void* dh, const void* h, void* dpre,
+                            long long n, float alpha, void* stream) {
+  if (n % 8) return CG_EINVAL;
+  const long long total8 = n / 8;
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid1d(total8, kThreads, 1LL << 31)),
+                     dim3(kThreads), 0, S_(stream), U16(dh), U16(h), U16W(dpre),
+                     alpha, total8);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_adam(float* p, const float* grad, float* m, float* v,
+                       long long n, float lr_t, float beta1, float beta2,
+                       float eps, float grad_scale, void* stream) {
+  if (n < 1) return CG_EINVAL;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, kThreads, 1LL << 31)),
+                     dim3(kThreads), 0, S_(stream), p, grad, m, v, n, lr_t,
+                     beta1, beta2, eps, grad_scale);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_signal_metrics(const float* real, const float* fake,
+                                 float* out, long long rows, int C, int Cr,
+                                 int Cf, float smin, float smax, void* stream) {
+  const int rows_per_wave = 16;
+  hipLaunchKernelGGL(signal_metrics_kernel,
+                     dim3(grid1d(rows, 4 * rows_per_wave, 1LL << 31)),
+                     dim3(kThreads), 0, S_(stream), real, fake, out, rows, C,
+                     Cr, Cf, smin, smax - smin, rows_per_wave);
+  CG_LAUNCH_CHECK();
+}

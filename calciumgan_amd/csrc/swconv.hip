@@ -1,0 +1,373 @@
+// Sliding-window convolution as an implicit GEMM on gfx950 MFMA.
+//
+// One kernel family serves every dense contraction of the CalciumGAN hot path
+// (reference call sites in include/calciumgan_hip.h):
+//   * Conv1D forward (stride 2, k taps)            -> R = 2
+//   * Conv1D input-gradient / Conv1DTranspose fwd  -> R = 1, k/2 taps, 2 phases
+//   * Conv1DTranspose input-gradient (stride 2)    -> R = 2
+//   * per-timestep Dense (taps = 1)                -> R = 1
+//
+// Data layout / tiling (DESIGN.md "swconv"):
+//   * activations are channels-last, so output row u needs ONE contiguous
+//     window of `taps` source rows; a tile of TM consecutive rows shares a
+//     window of (R*TM + taps - R) rows -> each source byte is staged into LDS
+//     once per tile and reused by up to taps/R output rows (no im2col).
+//   * stride-2 windows are de-interleaved by row parity while staging, so every
+//     tap becomes a stride-1 walk over one parity region: MFMA A fragments are
+//     single 16-byte ds_read_b128 with an odd 16-B-slot row pitch (bank-conflict
+//     free), and the channel chunk CK bounds LDS use.
+//   * the weight operand is pre-packed (cg_pack_weights) in exactly the K order
+//     the kernel walks, so a B stage is a contiguous 256-B-per-row copy.
+//   * block = 256 threads = 4 waves stacked along M; wave tile (16*MT) x 64,
+//     v_mfma_f32_16x16x32_bf16, fp32 accumulate; epilogue goes through LDS so
+//     global stores are 16-byte and row-contiguous, with bias / LeakyReLU /
+//     LeakyReLU-derivative mask / sigmoid fused.
+#include "cg_common.h"
+
+namespace {
+
+struct ConvArgs {
+  const uint16_t* x;
+  const uint16_t* w;
+  void* y;
+  const float* bias;
+  const uint16_t* mask;
+  const int* shifts;
+  int nB, Lx, Cx, seg_size;
+  int taps, off, Lu, M;
+  int N, Ly, Cy, y_stride, y_off;
+  int CK, c8, nchunks, Fp, nstages;
+  long long Kpack;
+  int pitchA, S, log2S, nseg, WR, ldsA_elems;
+  int epilogue, out_f32;
+  float alpha;
+  long long w_phase_stride;
+  int off_phase_step, yoff_phase_step;
+};
+
+constexpr int kPitchB = 136;          // 128 + 8 bf16: 17 16-B slots per row
+constexpr int kScrPitch = 68;         // fp32 epilogue scratch pitch
+constexpr int kLdsBBytes = 64 * kPitchB * 2;
+constexpr int kScratchBytes = 4 * 16 * kScrPitch * 4;
+
+template <int R, int MT>
+__global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TM = 64 * MT;
+  uint16_t* ldsA = reinterpret_cast<uint16_t*>(smem);
+  uint16_t* ldsB = ldsA + a.ldsA_elems;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r16 = lane & 15;
+  const int g = lane >> 4;
+  const int phase = blockIdx.z;
+  const uint16_t* __restrict__ wp = a.w + (long long)phase * a.w_phase_stride;
+  const int off = a.off + phase * a.off_phase_step;
+  const int y_off = a.y_off + phase * a.yoff_phase_step;
+  const int m0 = blockIdx.x * TM;
+  const int n0 = blockIdx.y * 64;
+  const int regionRows = a.nseg * a.WR;
+
+  int rowbase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int i = wave * 16 * MT + mt * 16 + r16;
+    const int seg = i >> a.log2S;
+    const int ui = i & (a.S - 1);
+    rowbase[mt] = (seg * a.WR + ui) * a.pitchA;
+  }
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int totalA = R * regionRows * a.c8;
+
+  for (int cc = 0; cc < a.nchunks; ++cc) {
+    __syncthreads();  // previous chunk's fragment reads are done
+    // ---- stage the source window of this channel chunk ------------------
+    for (int idx = tid; idx < totalA; idx += 256) {
+      const int row = idx / a.c8;
+      const int q8 = idx - row * a.c8;
+      const int rho = row / regionRows;
+      const int rem = row - rho * regionRows;
+      const int seg = rem / a.WR;
+      const int wr = rem - seg * a.WR;
+      const int mseg = m0 + seg * a.S;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (mseg < a.M) {
+        const int b = mseg / a.Lu;
+        const int u0 = mseg - b * a.Lu;
+        int srow = R * u0 + off + R * wr + rho;
+        if (srow >= 0 && srow < a.Lx) {
+          if (a.shifts) srow = shuffle_src(srow, a.shifts[b / a.seg_size], a.Lx);
+          const uint16_t* src =
+              a.x + ((long long)b * a.Lx + srow) * a.Cx + cc * a.CK + q8 * 8;
+          v = *reinterpret_cast<const uint4*>(src);
+        }
+      }
+      *reinterpret_cast<uint4*>(ldsA + row * a.pitchA + q8 * 8) = v;
+    }
+
+    // per-lane flattened K position inside the chunk: f = 4*kstep + g
+    int tap = 0, q8l = g;  // c8 >= 4
+    for (int s = 0; s < a.nstages; ++s) {
+      if (s > 0) __syncthreads();  // previous stage's B reads are done
+      // ---- stage 64 x 128 of the packed weight operand ------------------
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        const int n = idx >> 4;
+        const int f = idx & 15;
+        const uint16_t* src = wp + (long long)(n0 + n) * a.Kpack +
+                              ((long long)cc * a.Fp + 16 * s + f) * 8;
+        *reinterpret_cast<uint4*>(ldsB + n * kPitchB + f * 8) =
+            *reinterpret_cast<const uint4*>(src);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int t = tap < a.taps ? tap : a.taps - 1;  // padded K: B is zero
+        int aoff;
+        if (R == 2)
+          aoff = ((t & 1) * regionRows + (t >> 1)) * a.pitchA + q8l * 8;
+        else
+          aoff = t * a.pitchA + q8l * 8;
+        bf16x8 bfrag[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          bfrag[nt] = *reinterpret_cast<const bf16x8*>(
+              ldsB + (nt * 16 + r16) * kPitchB + (4 * ks + g) * 8);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const bf16x8 afrag =
+              *reinterpret_cast<const bf16x8*>(ldsA + rowbase[mt] + aoff);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                afrag, bfrag[nt], acc[mt][nt], 0, 0, 0);
+        }
+        q8l += 4;
+        if (q8l >= a.c8) {
+          q8l -= a.c8;
+          ++tap;
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: accumulators -> LDS -> row-contiguous 16-byte stores ----
+  __syncthreads();
+  float* scr = reinterpret_cast<float*>(smem) + wave * (16 * kScrPitch);
+  const int erow = lane >> 2;
+  const int ecol = (lane & 3) * 16;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        scr[(4 * g + r) * kScrPitch + nt * 16 + r16] = acc[mt][nt][r];
+    __syncthreads();
+    const int i = wave * 16 * MT + mt * 16 + erow;
+    const int m = m0 + i;
+    if (m < a.M) {
+      const int b = m / a.Lu;
+      const int u = m - b * a.Lu;
+      const long long rowoff =
+          ((long long)b * a.Ly + (long long)a.y_stride * u + y_off) * a.Cy;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int n = n0 + ecol + 8 * half;
+        if (n < a.Cy) {
+          float v[8];
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(
+              scr + erow * kScrPitch + ecol + 8 * half);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(
+              scr + erow * kScrPitch + ecol + 8 * half + 4);
+          v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
+          v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+          uint4 hm = make_uint4(0u, 0u, 0u, 0u);
+          if (a.epilogue == CG_EPI_MASK)
+            hm = *reinterpret_cast<const uint4*>(a.mask + rowoff + n);
+          const uint32_t hw[4] = {hm.x, hm.y, hm.z, hm.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = v[e];
+            if (n + e < a.N) {
+              if (a.bias) t += a.bias[n + e];
+              if (a.epilogue == CG_EPI_LRELU) {
+                t = t > 0.f ? t : a.alpha * t;
+              } else if (a.epilogue == CG_EPI_MASK) {
+                const uint16_t hb = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
+                t *= (bf2f(hb) > 0.f) ? 1.f : a.alpha;
+              } else if (a.epilogue == CG_EPI_SIGMOID) {
+                t = 1.f / (1.f + __expf(-t));
+              }
+            } else {
+              t = 0.f;
+            }
+            v[e] = t;
+          }
+          if (a.out_f32) {
+            float* dst = reinterpret_cast<float*>(a.y) + rowoff + n;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          } else {
+            uint16_t* dst = reinterpret_cast<uint16_t*>(a.y) + rowoff + n;
+            *reinterpret_cast<uint4*>(dst) =
+                make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
+                           pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------
+struct PackArgs {
+  const float* src;
+  uint16_t* dst;
+  int taps, tap0, tap_step;
+  long long s_tap, s_c, s_n;
+  int C_real, N_real, CK, c8, nchunks, Fp;
+  long long Kpack, total;
+};
+
+__global__ void pack_kernel(PackArgs a) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.total) return;
+  const int e = idx & 7;
+  long long r = idx >> 3;
+  const int f = (int)(r % a.Fp);
+  r /= a.Fp;
+  const int cc = (int)(r % a.nchunks);
+  const int n = (int)(r / a.nchunks);
+  const int tap = f / a.c8;
+  const int q8 = f - tap * a.c8;
+  const int c = cc * a.CK + q8 * 8 + e;
+  float v = 0.f;
+  if (tap < a.taps && c < a.C_real && n < a.N_real)
+    v = a.src[(long long)(a.tap0 + tap * a.tap_step) * a.s_tap + c * a.s_c +
+              n * a.s_n];
+  a.dst[idx] = f2bf(v);
+}
+
+inline int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+}  // namespace
+
+extern "C" int cg_abi_version(void) { return CG_ABI_VERSION; }
+
+extern "C" long long cg_packed_elems(int N, int taps, int Cx, int CK) {
+  if (CK < 32 || CK % 8 || Cx % CK || taps < 1 || N < 1) return -1;
+  const int c8 = CK / 8;
+  const int Fp = (taps * c8 + 15) / 16 * 16;
+  const long long Npad = (N + 63) / 64 * 64;
+  return Npad * (long long)(Cx / CK) * Fp * 8;
+}
+
+extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {
+  const long long total = cg_packed_elems(d->N_real, d->taps, d->Cx, d->CK);
+  if (total < 0 || d->C_real > d->Cx) return CG_EINVAL;
+  PackArgs a;
+  a.src = d->src;
+  a.dst = reinterpret_cast<uint16_t*>(d->dst);
+  a.taps = d->taps; a.tap0 = d->tap0; a.tap_step = d->tap_step;
+  a.s_tap = d->s_tap; a.s_c = d->s_c; a.s_n = d->s_n;
+  a.C_real = d->C_real; a.N_real = d->N_real; a.CK = d->CK;
+  a.c8 = d->CK / 8; a.nchunks = d->Cx / d->CK;
+  a.Fp = (d->taps * a.c8 + 15) / 16 * 16;
+  a.Kpack = (long long)a.nchunks * a.Fp * 8;
+  a.total = total;
+  const int threads = 256;
+  const long long blocks = (total + threads - 1) / threads;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(threads), 0,
+                     (hipStream_t)stream, a);
+  CG_LAUNCH_CHECK();
+}
+
+template <int R, int MT>
+static int launch_swconv(const ConvArgs& a, dim3 grid, size_t lds,
+                         hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&swconv_kernel<R, MT>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((swconv_kernel<R, MT>), grid, dim3(256), lds, stream, a);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
+  if (!d || !d->x || !d->w || !d->y) return CG_EINVAL;
+  if (d->stride != 1 && d->stride != 2) return CG_EINVAL;
+  if (d->stride == 2 && (d->taps & 1)) return CG_EINVAL;
+  if (d->CK < 32 || d->CK % 8 || d->Cx % d->CK || d->Cy % 8) return CG_EINVAL;
+  if (d->taps < 1 || d->Lu < 1 || d->nB < 1 || d->N < 1 || d->N > d->Cy)
+    return CG_EINVAL;
+  if (d->nphase != 1 && d->nphase != 2) return CG_EINVAL;
+  if (d->epilogue == CG_EPI_MASK && !d->mask_src) return CG_EINVAL;
+  if (d->shifts && d->seg_size < 1) return CG_EINVAL;
+  const int R = d->stride;
+  const int TM = d->small_tile ? 64 : 256;
+  int S;
+  if (d->Lu >= TM) {
+    if (d->Lu % TM) return CG_EINVAL;
+    S = TM;
+  } else {
+    if (TM % d->Lu) return CG_EINVAL;
+    S = d->Lu;
+  }
+  ConvArgs a;
+  a.x = reinterpret_cast<const uint16_t*>(d->x);
+  a.w = reinterpret_cast<const uint16_t*>(d->w);
+  a.y = d->y;
+  a.bias = d->bias;
+  a.mask = reinterpret_cast<const uint16_t*>(d->mask_src);
+  a.shifts = d->shifts;
+  a.nB = d->nB; a.Lx = d->Lx; a.Cx = d->Cx; a.seg_size = d->seg_size;
+  a.taps = d->taps; a.off = d->off; a.Lu = d->Lu;
+  a.M = d->nB * d->Lu;
+  a.N = d->N; a.Ly = d->Ly; a.Cy = d->Cy; a.y_stride = d->y_stride;
+  a.y_off = d->y_off;
+  a.CK = d->CK; a.c8 = d->CK / 8; a.nchunks = d->Cx / d->CK;
+  a.Fp = (d->taps * a.c8 + 15) / 16 * 16;
+  a.nstages = a.Fp / 16;
+  a.Kpack = (long long)a.nchunks * a.Fp * 8;
+  a.pitchA = d->CK + ((a.c8 & 1) ? 16 : 8);
+  a.S = S; a.log2S = ilog2(S); a.nseg = TM / S;
+  a.WR = S + d->taps / R - 1;
+  a.ldsA_elems = R * a.nseg * a.WR * a.pitchA;
+  a.epilogue = d->epilogue; a.out_f32 = d->out_f32; a.alpha = d->alpha;
+  a.w_phase_stride = d->w_phase_stride;
+  a.off_phase_step = d->off_phase_step;
+  a.yoff_phase_step = d->yoff_phase_step;
+  size_t ldsA_bytes = (size_t)a.ldsA_elems * 2;
+  if (ldsA_bytes < (size_t)kScratchBytes) ldsA_bytes = kScratchBytes;
+  ldsA_bytes = (ldsA_bytes + 15) / 16 * 16;
+  a.ldsA_elems = (int)(ldsA_bytes / 2);
+  const size_t lds = ldsA_bytes + kLdsBBytes;
+  if (lds > 160 * 1024) return CG_EINVAL;
+  dim3 grid((a.M + TM - 1) / TM, (d->N + 63) / 64, d->nphase);
+  hipStream_t s = (hipStream_t)stream;
+  if (R == 1 && !d->small_tile) return launch_swconv<1, 4>(a, grid, lds, s);
+  if (R == 1 && d->small_tile) return launch_swconv<1, 1>(a, grid, lds, s);
+  if (R == 2 && !d->small_tile) return launch_swconv<2, 4>(a, grid, lds, s);
+  return launch_swconv<2, 1>(a, grid, lds, s);
+}

@@ -1,0 +1,248 @@
+// Weight gradient of the sliding-window convolution on gfx950 MFMA.
+//
+//   dw[tap][cx][cg] += sum_{b,u} xs[b, R*u + off + tap, cx] * g[b, u, cg]
+//
+// GEMM view: M' = (tap, cx), N' = cg, K' = (b, u).  Both operands are
+// channels-last, i.e. K'-strided, so the MFMA fragments come from
+// ds_read_b64_tr_b16 (hardware 4x16 transpose read) on row-major LDS images:
+//   * a tile of TT consecutive (b,u) rows stages g[TT][64] and the matching x
+//     window (R*TT + taps - R rows x 32 channels, de-interleaved by row parity
+//     for R = 2 so a tap walks stride-1 rows);
+//   * block = 512 threads = 8 waves; for taps > 1 wave w owns taps w, w+8,
+//     w+16 and keeps their 32x64 f32 accumulators (<= 96 VGPRs) for the whole
+//     K' sweep, so x and g tiles are read once from HBM/L2 per (cx,cg) block;
+//     for taps == 1 (Dense) the 8 waves split the 256 staged rows instead;
+//   * K' is split over blockIdx.z; partial sums land with f32 atomics
+//     (row-contiguous 64-B segments).
+// LDS pitches are 32*odd bytes so each 32-lane half of a tr-read touches 8
+// distinct 32-B bank groups (conflict-free).
+#include "cg_common.h"
+
+namespace {
+
+struct WgradArgs {
+  const uint16_t* x;
+  const uint16_t* g;
+  float* dw;
+  const int* shifts;
+  int nB, Lx, Cx, seg_size;
+  int Lu, Cg, M;
+  int taps, off;
+  int Cx_real, Cg_real;
+  int S, log2S, nseg, WR;
+  int ntiles;
+};
+
+constexpr int kPitchX = 48;  // 32 ch + 16 pad  (96 B = 32*3)
+constexpr int kPitchG = 80;  // 64 ch + 16 pad  (160 B = 32*5)
+
+__device__ __forceinline__ s16x4 tr_read(const uint16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(p));
+}
+
+__device__ __forceinline__ bf16x8 join(s16x4 lo, s16x4 hi) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// R: source stride (1|2).  TPW: taps per wave.  ROWSPLIT: taps == 1, the waves
+// split the staged rows (TT = 256) instead of the taps (TT = 64).
+template <int R, int TPW, bool ROWSPLIT>
+__global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TT = ROWSPLIT ? 256 : 64;
+  const int regionRows = a.nseg * a.WR;
+  uint16_t* ldsX = reinterpret_cast<uint16_t*>(smem);
+  uint16_t* ldsG = ldsX + R * regionRows * kPitchX;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r16 = lane & 15;
+  const int g4 = lane >> 4;
+  const int q = r16 >> 2;
+  const int p = r16 & 3;
+  const int cx0 = blockIdx.x * 32;
+  const int cg0 = blockIdx.y * 64;
+
+  f32x4 acc[TPW][2][4];
+#pragma unroll
+  for (int s = 0; s < TPW; ++s)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[s][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int totalX = R * regionRows * 4;
+  const int totalG = TT * 8;
+
+  for (int tile = blockIdx.z; tile < a.ntiles; tile += gridDim.z) {
+    const int m0 = tile * TT;
+    __syncthreads();
+    for (int idx = tid; idx < totalX; idx += 512) {
+      const int row = idx >> 2;
+      const int q8 = idx & 3;
+      const int rho = row / regionRows;
+      const int rem = row - rho * regionRows;
+      const int seg = rem / a.WR;
+      const int wr = rem - seg * a.WR;
+      const int mseg = m0 + seg * a.S;
+      const int c = cx0 + q8 * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (mseg < a.M && c < a.Cx) {
+        const int b = mseg / a.Lu;
+        const int u0 = mseg - b * a.Lu;
+        int srow = R * u0 + a.off + R * wr + rho;
+        if (srow >= 0 && srow < a.Lx) {
+          if (a.shifts) srow = shuffle_src(srow, a.shifts[b / a.seg_size], a.Lx);
+          v = *reinterpret_cast<const uint4*>(
+              a.x + ((long long)b * a.Lx + srow) * a.Cx + c);
+        }
+      }
+      *reinterpret_cast<uint4*>(ldsX + row * kPitchX + q8 * 8) = v;
+    }
+    for (int idx = tid; idx < totalG; idx += 512) {
+      const int row = idx >> 3;
+      const int q8 = idx & 7;
+      const int m = m0 + row;
+      const int c = cg0 + q8 * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (m < a.M && c < a.Cg)
+        v = *reinterpret_cast<const uint4*>(a.g + (long long)m * a.Cg + c);
+      *reinterpret_cast<uint4*>(ldsG + row * kPitchG + q8 * 8) = v;
+    }
+    __syncthreads();
+
+    constexpr int KSTEPS = ROWSPLIT ? 1 : 2;
+#pragma unroll
+    for (int kstep = 0; kstep < KSTEPS; ++kstep) {
+      const int rbase = ROWSPLIT ? wave * 32 : kstep * 32;
+      // tile rows of this lane's two transposed reads (k = 8*g4 + 4*h + q')
+      const int i0 = rbase + 4 * g4 + q;
+      const int i1 = i0 + 16;
+      bf16x8 bfrag[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        bfrag[nt] = join(tr_read(ldsG + i0 * kPitchG + nt * 16 + 4 * p),
+                         tr_read(ldsG + i1 * kPitchG + nt * 16 + 4 * p));
+      const int x0 = ((i0 >> a.log2S) * a.WR + (i0 & (a.S - 1))) * kPitchX;
+      const int x1 = ((i1 >> a.log2S) * a.WR + (i1 & (a.S - 1))) * kPitchX;
+#pragma unroll
+      for (int s = 0; s < TPW; ++s) {
+        const int tap = ROWSPLIT ? 0 : wave + 8 * s;
+        if (tap < a.taps) {  // wave-uniform
+          int toff;
+          if (R == 2)
+            toff = ((tap & 1) * regionRows + (tap >> 1)) * kPitchX;
+          else
+            toff = tap * kPitchX;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const bf16x8 afrag =
+                join(tr_read(ldsX + x0 + toff + mt * 16 + 4 * p),
+                     tr_read(ldsX + x1 + toff + mt * 16 + 4 * p));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              acc[s][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  afrag, bfrag[nt], acc[s][mt][nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int s = 0; s < TPW; ++s) {
+    const int tap = ROWSPLIT ? 0 : wave + 8 * s;
+    if (tap >= a.taps) continue;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cx = cx0 + mt * 16 + 4 * g4 + r;
+          const int cg = cg0 + nt * 16 + r16;
+          if (cx < a.Cx_real && cg < a.Cg_real)
+            atomicAdd(a.dw + ((long long)tap * a.Cx_real + cx) * a.Cg_real + cg,
+                      acc[s][mt][nt][r]);
+        }
+  }
+}
+
+inline int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+template <int R, int TPW, bool ROWSPLIT>
+int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&wgrad_kernel<R, TPW, ROWSPLIT>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<R, TPW, ROWSPLIT>), grid, dim3(512), lds, s,
+                     a);
+  CG_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+extern "C" int cg_wgrad(const cg_wgrad_desc* d, void* stream) {
+  if (!d || !d->x || !d->g || !d->dw) return CG_EINVAL;
+  const bool rowsplit = d->taps == 1;
+  if (rowsplit) {
+    if (d->stride != 1) return CG_EINVAL;
+  } else {
+    if (d->stride != 2 || (d->taps & 1) || d->taps > 24) return CG_EINVAL;
+  }
+  if (d->Cx % 8 || d->Cg % 8 || d->Cx_real > d->Cx || d->Cg_real > d->Cg)
+    return CG_EINVAL;
+  if (d->shifts && d->seg_size < 1) return CG_EINVAL;
+  const int TT = rowsplit ? 256 : 64;
+  int S;
+  if (d->Lu >= TT) {
+    if (d->Lu % TT) return CG_EINVAL;
+    S = TT;
+  } else {
+    if (TT % d->Lu) return CG_EINVAL;
+    S = d->Lu;
+  }
+  WgradArgs a;
+  a.x = reinterpret_cast<const uint16_t*>(d->x);
+  a.g = reinterpret_cast<const uint16_t*>(d->g);
+  a.dw = d->dw;
+  a.shifts = d->shifts;
+  a.nB = d->nB; a.Lx = d->Lx; a.Cx = d->Cx; a.seg_size = d->seg_size;
+  a.Lu = d->Lu; a.Cg = d->Cg; a.M = d->nB * d->Lu;
+  a.taps = d->taps; a.off = d->off;
+  a.Cx_real = d->Cx_real; a.Cg_real = d->Cg_real;
+  a.S = S; a.log2S = ilog2(S); a.nseg = TT / S;
+  const int R = d->stride;
+  a.WR = S + d->taps / R - 1;
+  a.ntiles = (a.M + TT - 1) / TT;
+  const size_t lds =
+      ((size_t)R * a.nseg * a.WR * kPitchX + (size_t)TT * kPitchG) * 2;
+  if (lds > 160 * 1024) return CG_EINVAL;
+  const int gx = (d->Cx_real + 31) / 32;
+  const int gy = (d->Cg_real + 63) / 64;
+  int nsplit = d->nsplit;
+  if (nsplit <= 0) {
+    nsplit = (1024 + gx * gy - 1) / (gx * gy);  // ~4 blocks per CU
+  }
+  if (nsplit > a.ntiles) nsplit = a.ntiles;
+  if (nsplit < 1) nsplit = 1;
+  dim3 grid(gx, gy, nsplit);
+  hipStream_t s = (hipStream_t)stream;
+  if (rowsplit) return launch_wgrad<1, 1, true>(a, grid, lds, s);
+  if (d->taps <= 8) return launch_wgrad<2, 1, false>(a, grid, lds, s);
+  if (d->taps <= 16) return launch_wgrad<2, 2, false>(a, grid, lds, s);
+  return launch_wgrad<2, 3, false>(a, grid, lds, s);
+}

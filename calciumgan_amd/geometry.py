@@ -1,0 +1,142 @@
+"""Host-side shape logic of the CalciumGAN stack (pure python, CPU-testable).
+
+Restates the shape rules of gan/models/calciumgan.py (generator :22-103,
+discriminator :141-192, calculate_noise_shape :15-19) and adds the MI355X
+layout decisions: channel pitch, channel-chunk (CK) of the packed MFMA operand
+and the tile choice of cg_swconv.
+"""
+from collections import namedtuple
+
+NUM_CONVS = 5
+LDS_BYTES = 160 * 1024
+_LDS_B = 64 * 136 * 2
+_SCRATCH = 4 * 16 * 68 * 4
+
+
+def round_up(v, m):
+  return (v + m - 1) // m * m
+
+
+def pitch(channels):
+  """Channel pitch of a bf16 activation: multiple of 8 (16-byte rows), at least
+  32 (smallest MFMA K chunk); above 128 a multiple of 32 so a 32/64 chunk
+  divides it."""
+  if channels <= 128:
+    return max(32, round_up(channels, 8))
+  return round_up(channels, 32)
+
+
+def calculate_noise_shape(output_shape, noise_dim, num_convolutions, strides):
+  """calciumgan.py:15-19."""
+  w = output_shape[0] / (strides**num_convolutions)
+  if not float(w).is_integer():
+    raise ValueError('Conv1D: w {} is not an integer.'.format(w))
+  return (int(w), noise_dim)
+
+
+def same_padding_left(kernel_size, strides):
+  """TF 'same' left pad for even input lengths: (k - s) // 2."""
+  return max(kernel_size - strides, 0) // 2
+
+
+def tile_rows(Lu, M, n_tiles_n):
+  """Row tile of cg_swconv: 256 when the per-sample length allows it and the
+  launch still has >= 256 workgroups, else 64.  Returns (small_tile, TM)."""
+  def ok(tm):
+    return (Lu % tm == 0) if Lu >= tm else (tm % Lu == 0)
+  if ok(256) and (M // 256) * n_tiles_n >= 256:
+    return 0, 256
+  if ok(64):
+    return 1, 64
+  if ok(256):
+    return 0, 256
+  raise ValueError(
+      'unsupported per-sample length {} (must be a power of two <= 64 or a '
+      'multiple of 64)'.format(Lu))
+
+
+def lds_bytes(CK, stride, taps, Lu, TM):
+  c8 = CK // 8
+  pitch_a = CK + (16 if c8 & 1 else 8)
+  S = min(Lu, TM)
+  nseg = TM // S
+  WR = S + taps // stride - 1
+  a = max(stride * nseg * WR * pitch_a * 2, _SCRATCH)
+  return round_up(a, 16) + _LDS_B
+
+
+def choose_ck(Cx, stride, taps, Lu, TM):
+  """Channel chunk of the packed operand: a divisor of the pitch, multiple of
+  8, >= 32; prefer the largest <= 64 (two workgroups per CU), fall back to
+  larger chunks when the pitch has no such divisor (e.g. 104)."""
+  cands = [d for d in range(32, Cx + 1, 8) if Cx % d == 0]
+  pref = sorted([d for d in cands if d <= 64], reverse=True) + sorted(
+      [d for d in cands if d > 64])
+  for d in pref:
+    if lds_bytes(d, stride, taps, Lu, TM) <= LDS_BYTES:
+      return d
+  raise ValueError('no channel chunk fits LDS for Cx={} taps={} Lu={}'.format(
+      Cx, taps, Lu))
+
+
+ConvLayer = namedtuple('ConvLayer', 'cin cout lin lout cinp coutp')
+
+
+def discriminator_layers(hp):
+  """Conv1D(k, s, 'same') x5 with filters U..5U (calciumgan.py:145-185)."""
+  u = hp.num_units
+  filters = [u, 2 * u, 3 * u, 4 * u, 5 * u]
+  layers = []
+  cin, length = hp.num_channels, hp.signal_shape[0]
+  for cout in filters:
+    if length % hp.strides:
+      raise ValueError('sequence length not divisible by strides**5')
+    lout = length // hp.strides
+    layers.append(ConvLayer(cin, cout, length, lout, pitch(cin), pitch(cout)))
+    cin, length = cout, lout
+  return layers
+
+
+def generator_layers(hp):
+  """Conv1DTranspose x5 with filters 5U..2U, C (calciumgan.py:37-87)."""
+  u = hp.num_units
+  filters = [5 * u, 4 * u, 3 * u, 2 * u, hp.num_channels]
+  w, nd = calculate_noise_shape(hp.signal_shape, hp.noise_dim, NUM_CONVS,
+                                hp.strides)
+  layers = []
+  cin, length = nd, w
+  for cout in filters:
+    lout = length * hp.strides
+    layers.append(ConvLayer(cin, cout, length, lout, pitch(cin), pitch(cout)))
+    cin, length = cout, lout
+  return layers
+
+
+def validate_hparams(hp):
+  """Shapes the HIP path supports; raises ValueError like the reference does
+  for a non-integer noise width (calciumgan.py:17-18)."""
+  if hp.strides != 2:
+    raise ValueError('calciumgan_amd: only strides=2 is implemented in HIP')
+  if hp.kernel_size % 2 or hp.kernel_size > 24 or hp.kernel_size < 2:
+    raise ValueError('calciumgan_amd: kernel_size must be even and <= 24')
+  if hp.noise_dim % 8 or hp.noise_dim < 32:
+    raise ValueError('calciumgan_amd: noise_dim must be a multiple of 8, >= 32')
+  if getattr(hp, 'batch_norm', False):
+    raise ValueError('calciumgan_amd: batch_norm is not supported '
+                     '(needs cross-rank statistics under data parallelism)')
+  if getattr(hp, 'activation', 'leakyrelu') != 'leakyrelu':
+    raise ValueError('calciumgan_amd: only activation=leakyrelu is implemented')
+  w, _ = calculate_noise_shape(hp.signal_shape, hp.noise_dim, NUM_CONVS,
+                               hp.strides)
+  for lay in discriminator_layers(hp):
+    lu = lay.lout
+    if not ((lu % 64 == 0) or (64 % lu == 0)):
+      raise ValueError(
+          'calciumgan_amd: layer length {} unsupported (sequence_length/32 must '
+          'be a power of two or a multiple of 64)'.format(lu))
+  # tf.pad(mode='reflect') needs pad < length: PhaseShuffle on the layer-4
+  # output (length L/16) bounds m (calciumgan.py:126-135)
+  if hp.m >= hp.signal_shape[0] // 16:
+    raise ValueError('phase shuffle m={} too large for sequence length'.format(
+        hp.m))
+  return w

@@ -1,0 +1,634 @@
+"""Device-side state and kernel schedules of the CalciumGAN generator and
+discriminator (reference: gan/models/calciumgan.py:22-103, :141-192).
+
+PyTorch is plumbing only here: it owns device memory, the stream and (in
+parallel.py) the RCCL process group.  Every arithmetic step is a call into the
+gfx950 kernel library through the C ABI (include/calciumgan_hip.h); launch
+descriptors are built once per batch size and replayed.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import geometry as geo
+from ._lib import ConvDesc, PackDesc, WgradDesc
+
+BF16 = torch.bfloat16
+LEAKY_ALPHA = 0.3  # Keras LeakyReLU() default; gan/models/utils.py:6-8
+LN_EPS = 1e-3  # Keras LayerNormalization default epsilon
+
+
+def _p(t):
+  return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu():
+  _lib.load()  # raises HipLibraryError when the extension is missing
+  if not torch.cuda.is_available():
+    raise RuntimeError(
+        'calciumgan_amd: no HIP device visible; the MI355X kernels are the only '
+        'compute path (no CPU fallback)')
+
+
+class FlatParams(object):
+  """All parameters of one model in ONE flat f32 buffer (one Adam launch, one
+  RCCL all-reduce), with per-tensor views in Keras get_weights() order."""
+
+  def __init__(self, shapes, device):
+    self.shapes = [tuple(s) for s in shapes]
+    sizes = [int(np.prod(s)) for s in self.shapes]
+    # 16-byte align every tensor so vector loads stay aligned
+    self.offsets = []
+    off = 0
+    for n in sizes:
+      self.offsets.append(off)
+      off += geo.round_up(n, 4)
+    self.numel = off
+    self.count = int(sum(sizes))
+    self.data = torch.zeros(off, dtype=torch.float32, device=device)
+    self.grad = torch.zeros_like(self.data)
+    self.m = torch.zeros_like(self.data)
+    self.v = torch.zeros_like(self.data)
+    self.views = [
+        self.data[o:o + n].view(s)
+        for o, n, s in zip(self.offsets, sizes, self.shapes)
+    ]
+    self.grad_views = [
+        self.grad[o:o + n].view(s)
+        for o, n, s in zip(self.offsets, sizes, self.shapes)
+    ]
+
+  def get_weights(self):
+    return [v.detach().cpu().numpy().copy() for v in self.views]
+
+  def set_weights(self, weights):
+    if len(weights) != len(self.views):
+      raise ValueError('expected {} arrays, got {}'.format(
+          len(self.views), len(weights)))
+    for v, w in zip(self.views, weights):
+      w = np.asarray(w, dtype=np.float32)
+      if tuple(w.shape) != tuple(v.shape):
+        raise ValueError('shape mismatch {} vs {}'.format(w.shape, v.shape))
+      v.copy_(torch.from_numpy(w))
+
+
+class PackedOperand(object):
+  """bf16 MFMA operand of one (layer, direction), produced from the f32 master
+  tensor by cg_pack_weights in the K order cg_swconv walks."""
+
+  def __init__(self, src, phases, C_real, N_real, Cx, CK, taps):
+    lib = _lib.load()
+    self.elems = lib.cg_packed_elems(N_real, taps, Cx, CK)
+    if self.elems < 0:
+      raise ValueError('bad packing geometry')
+    self.taps, self.Cx, self.CK, self.N = taps, Cx, CK, N_real
+    self.nphase = len(phases)
+    self.buf = torch.zeros(
+        self.nphase * self.elems, dtype=BF16, device=src.device)
+    self.src = src
+    self.descs = []
+    for i, (tap0, tap_step, s_tap, s_c, s_n) in enumerate(phases):
+      d = PackDesc()
+      d.src = src.data_ptr()
+      d.dst = self.buf.data_ptr() + 2 * i * self.elems
+      d.taps, d.tap0, d.tap_step = taps, tap0, tap_step
+      d.s_tap, d.s_c, d.s_n = s_tap, s_c, s_n
+      d.C_real, d.N_real, d.Cx, d.CK = C_real, N_real, Cx, CK
+      self.descs.append(d)
+
+  def repack(self):
+    st = _stream()
+    for d in self.descs:
+      _lib.call('cg_pack_weights', ctypes.byref(d), st)
+
+
+def _transpose_phases(k, pad_left):
+  """Tap walk of the two output phases of a stride-2 transposed convolution
+  (SURVEY Appendix A.2): out[2u+p] = sum_jj src[u + off_p + jj] * W[tap0_p - 2jj].
+  Returns [(tap0, off)] for p = 0, 1."""
+  out = []
+  for p in (0, 1):
+    kk0 = (p + pad_left) & 1
+    off = (p + pad_left - kk0) // 2 - (k // 2 - 1)
+    out.append((kk0 + k - 2, off))
+  return out
+
+
+def _ck_for(Cx, stride, taps, Lu):
+  """One CK valid for both row tiles the launcher may pick for this layer."""
+  cands = [d for d in range(32, Cx + 1, 8) if Cx % d == 0]
+  pref = sorted([d for d in cands if d <= 64], reverse=True) + sorted(
+      [d for d in cands if d > 64])
+  tms = [tm for tm in (256, 64)
+         if ((Lu % tm == 0) if Lu >= tm else (tm % Lu == 0))]
+  if not tms:
+    raise ValueError('unsupported per-sample length {}'.format(Lu))
+  for d in pref:
+    if all(geo.lds_bytes(d, stride, taps, Lu, tm) <= geo.LDS_BYTES for tm in tms):
+      return d
+  # fall back to the small tile only
+  for d in pref:
+    if geo.lds_bytes(d, stride, taps, Lu, 64) <= geo.LDS_BYTES:
+      return d
+  raise ValueError('no channel chunk fits LDS (Cx={}, taps={})'.format(Cx, taps))
+
+
+def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
+               y_stride=1, y_off=0, bias=None, mask_src=None, shifts=None,
+               seg_size=1, epilogue=_lib.EPI_NONE, out_f32=False, nphase=1,
+               w_phase_stride=0, off_phase_step=0, yoff_phase_step=0):
+  d = ConvDesc()
+  d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+  d.bias = bias.data_ptr() if bias is not None else None
+  d.mask_src = mask_src.data_ptr() if mask_src is not None else None
+  d.shifts = shifts.data_ptr() if shifts is not None else None
+  d.nB, d.Lx, d.Cx, d.seg_size = nB, Lx, Cx, seg_size
+  d.taps, d.stride, d.off, d.Lu = taps, stride, off, Lu
+  d.N, d.Ly, d.Cy, d.y_stride, d.y_off = N, Ly, Cy, y_stride, y_off
+  d.CK = CK
+  d.epilogue, d.out_f32, d.alpha = epilogue, int(out_f32), LEAKY_ALPHA
+  d.nphase, d.w_phase_stride = nphase, w_phase_stride
+  d.off_phase_step, d.yoff_phase_step = off_phase_step, yoff_phase_step
+  n_tiles_n = (N + 63) // 64
+  small, tm = geo.tile_rows(Lu, nB * Lu, n_tiles_n * nphase)
+  if geo.lds_bytes(CK, stride, taps, Lu, tm) > geo.LDS_BYTES:
+    small, tm = 1, 64
+  d.small_tile = small
+  return d
+
+
+def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,
+                Cg_real, shifts=None, seg_size=1):
+  d = WgradDesc()
+  d.x, d.g, d.dw = x.data_ptr(), g.data_ptr(), dw.data_ptr()
+  d.shifts = shifts.data_ptr() if shifts is not None else None
+  d.nB, d.Lx, d.Cx, d.seg_size = nB, Lx, Cx, seg_size
+  d.Lu, d.Cg = Lu, Cg
+  d.taps, d.stride, d.off = taps, stride, off
+  d.Cx_real, d.Cg_real = Cx_real, Cg_real
+  d.nsplit = 0
+  return d
+
+
+def _run_conv(d, st):
+  _lib.call('cg_swconv', ctypes.byref(d), st)
+
+
+def _run_wgrad(d, st):
+  _lib.call('cg_wgrad', ctypes.byref(d), st)
+
+
+def glorot_uniform(rng, shape, fan_in, fan_out):
+  limit = math.sqrt(6.0 / (fan_in + fan_out))
+  return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+# ===========================================================================
+# Discriminator
+# ===========================================================================
+class DiscriminatorNet(object):
+  """5 x [Conv1D(k, s=2, 'same') -> LeakyReLU -> PhaseShuffle] -> Flatten ->
+  Dense(1)  (calciumgan.py:141-192)."""
+
+  def __init__(self, hp, device, rng):
+    _require_gpu()
+    geo.validate_hparams(hp)
+    self.hp = hp
+    self.device = device
+    self.k = hp.kernel_size
+    self.pl = geo.same_padding_left(self.k, hp.strides)
+    self.layers = geo.discriminator_layers(hp)
+    shapes = []
+    for lay in self.layers:
+      shapes += [(self.k, lay.cin, lay.cout), (lay.cout,)]
+    last = self.layers[-1]
+    self.flat = last.lout * last.cout
+    shapes += [(self.flat, 1), (1,)]
+    self.params = FlatParams(shapes, device)
+    init = []
+    for lay in self.layers:
+      init.append(
+          glorot_uniform(rng, (self.k, lay.cin, lay.cout), self.k * lay.cin,
+                         self.k * lay.cout))
+      init.append(np.zeros(lay.cout, np.float32))
+    init.append(glorot_uniform(rng, (self.flat, 1), self.flat, 1))
+    init.append(np.zeros(1, np.float32))
+    self.params.set_weights(init)
+    # packed operands
+    self.w_fwd, self.w_dgrad = [], []
+    phases = _transpose_phases(self.k, self.pl)
+    self.dgrad_offs = [o for _, o in phases]
+    for i, lay in enumerate(self.layers):
+      W = self.params.views[2 * i]
+      ci, co = lay.cin, lay.cout
+      ck = _ck_for(lay.cinp, 2, self.k, lay.lout)
+      self.w_fwd.append(
+          PackedOperand(W, [(0, 1, ci * co, co, 1)], ci, co, lay.cinp, ck,
+                        self.k))
+      ck = _ck_for(lay.coutp, 1, self.k // 2, lay.lin // 2)
+      self.w_dgrad.append(
+          PackedOperand(W, [(t0, -2, ci * co, 1, co) for t0, _ in phases], co,
+                        ci, lay.coutp, ck, self.k // 2))
+    self.repack()
+    self._ws = {}
+
+  # -- parameters ---------------------------------------------------------
+  def repack(self):
+    for op in self.w_fwd + self.w_dgrad:
+      op.repack()
+
+  @property
+  def dense_w(self):
+    return self.params.views[-2]
+
+  @property
+  def dense_b(self):
+    return self.params.views[-1]
+
+  # -- workspace ----------------------------------------------------------
+  def workspace(self, nB):
+    ws = self._ws.get(nB)
+    if ws is None:
+      ws = _DisWorkspace(self, nB)
+      self._ws[nB] = ws
+    return ws
+
+
+class _DisWorkspace(object):
+  """Activations / gradients of the discriminator for a batch of nB samples and
+  the launch descriptors over them (also for sub-batches that start at sample
+  0 or at a segment boundary)."""
+
+  def __init__(self, net, nB):
+    dev = net.device
+    self.net = net
+    self.nB = nB
+    L0 = net.layers[0].lin
+    cp0 = net.layers[0].cinp
+    z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)
+    self.act = [z(nB, L0, cp0)] + [z(nB, l.lout, l.coutp) for l in net.layers]
+    self.e = [None] + [z(nB, l.lout, l.coutp) for l in net.layers[:-1]]
+    self.delta = [None] + [z(nB, l.lout, l.coutp) for l in net.layers]
+    self.d_out = z(nB, dt=torch.float32)
+    self._plans = {}
+
+  def plan(self, nB, seg_size, input_grad_from):
+    """Descriptors for a run over the first nB samples with shift segments of
+    seg_size samples; the layer-1 input gradient is computed for samples
+    [input_grad_from, nB) (None = not at all)."""
+    key = (nB, seg_size, input_grad_from)
+    pl = self._plans.get(key)
+    if pl is None:
+      pl = _DisPlan(self, nB, seg_size, input_grad_from)
+      self._plans[key] = pl
+    return pl
+
+
+class _DisPlan(object):
+
+  def __init__(self, ws, nB, seg_size, input_grad_from):
+    net = ws.net
+    dev = net.device
+    self.ws, self.nB, self.seg_size = ws, nB, seg_size
+    self.nseg = (nB + seg_size - 1) // seg_size
+    k, pl = net.k, net.pl
+    # shifts[l][seg]: PhaseShuffle draw applied after layer l+1 (l = 0..3)
+    self.shifts = torch.zeros(4, self.nseg, dtype=torch.int32, device=dev)
+    self.coef = torch.zeros(self.nseg, dtype=torch.float32, device=dev)
+    self.bias_coef = torch.zeros(self.nseg, dtype=torch.float32, device=dev)
+    self.fwd, self.dgrad, self.jvp, self.wgrad = [], [], [], []
+    for i, lay in enumerate(net.layers):
+      sh = self.shifts[i - 1] if i > 0 else None
+      bias = net.params.views[2 * i + 1]
+      op = net.w_fwd[i]
+      self.fwd.append(
+          _conv_desc(ws.act[i], op.buf, ws.act[i + 1], nB, lay.lin, lay.cinp, k,
+                     2, -pl, lay.lout, lay.cout, lay.lout, lay.coutp, op.CK,
+                     bias=bias, shifts=sh, seg_size=seg_size,
+                     epilogue=_lib.EPI_LRELU))
+      self.wgrad.append(
+          _wgrad_desc(ws.act[i], ws.delta[i + 1], net.params.grad_views[2 * i],
+                      nB, lay.lin, lay.cinp, lay.lout, lay.coutp, k, 2, -pl,
+                      lay.cin, lay.cout, shifts=sh, seg_size=seg_size))
+    # input-gradient chain: layer i (1-based l = i+1) maps delta[l] -> e[l-1]
+    for i in range(len(net.layers) - 1, 0, -1):
+      lay = net.layers[i]
+      op = net.w_dgrad[i]
+      self.dgrad.append((i,
+                         _conv_desc(ws.delta[i + 1], op.buf, ws.e[i], nB,
+                                    lay.lout, lay.coutp, k // 2, 1,
+                                    net.dgrad_offs[0], lay.lin // 2, lay.cin,
+                                    lay.lin, lay.cinp, op.CK, y_stride=2,
+                                    y_off=0, nphase=2,
+                                    w_phase_stride=op.elems,
+                                    off_phase_step=net.dgrad_offs[1] -
+                                    net.dgrad_offs[0], yoff_phase_step=1)))
+    self.input_grad = None
+    self.gin = None
+    if input_grad_from is not None:
+      lay = net.layers[0]
+      op = net.w_dgrad[0]
+      nG = nB - input_grad_from
+      self.nG = nG
+      self.gin = torch.zeros(
+          nG, lay.lin, lay.cinp, dtype=torch.float32, device=dev)
+      self.input_grad = _conv_desc(
+          ws.delta[1][input_grad_from:], op.buf, self.gin, nG, lay.lout,
+          lay.coutp, k // 2, 1, net.dgrad_offs[0], lay.lin // 2, lay.cin,
+          lay.lin, lay.cinp, op.CK, y_stride=2, y_off=0, out_f32=True, nphase=2,
+          w_phase_stride=op.elems,
+          off_phase_step=net.dgrad_offs[1] - net.dgrad_offs[0],
+          yoff_phase_step=1)
+
+  def build_jvp(self, seg_index):
+    """Tangent-forward chain (gradient-penalty second backward) over segment
+    seg_index, in place over that segment's activations."""
+    ws, net = self.ws, self.ws.net
+    s0 = seg_index * self.seg_size
+    n = min(self.seg_size, self.nB - s0)
+    k, pl = net.k, net.pl
+    self.jvp = []
+    for i, lay in enumerate(net.layers):
+      sh = self.shifts[i - 1][seg_index:] if i > 0 else None
+      op = net.w_fwd[i]
+      seg_act = ws.act[i + 1][s0:s0 + n]
+      self.jvp.append(
+          _conv_desc(ws.act[i][s0:s0 + n], op.buf, seg_act, n, lay.lin,
+                     lay.cinp, k, 2, -pl, lay.lout, lay.cout, lay.lout,
+                     lay.coutp, op.CK, mask_src=seg_act, shifts=sh,
+                     seg_size=n, epilogue=_lib.EPI_MASK))
+
+  # -- schedules ------------------------------------------------------------
+  def forward(self):
+    """act[0] (already filled) -> d_out[:nB]."""
+    st = _stream()
+    net, ws = self.ws.net, self.ws
+    for d in self.fwd:
+      _run_conv(d, st)
+    last = net.layers[-1]
+    _lib.call('cg_dense1_fwd', _p(ws.act[-1]), _p(net.dense_w), _p(net.dense_b),
+              _p(ws.d_out), self.nB, last.lout, last.cout, last.coutp, st)
+
+  def backward_chain(self):
+    """delta[5] = coef * w_d * lrelu'(h5); then down to delta[1]; optional
+    layer-1 input gradient into self.gin (f32)."""
+    st = _stream()
+    net, ws = self.ws.net, self.ws
+    last = net.layers[-1]
+    _lib.call('cg_dense1_bwd', _p(net.dense_w), _p(self.coef), _p(ws.act[-1]),
+              _p(ws.delta[-1]), self.nB, last.lout, last.cout, last.coutp,
+              self.seg_size, LEAKY_ALPHA, st)
+    for i, d in self.dgrad:
+      _run_conv(d, st)
+      lay = net.layers[i - 1]
+      _lib.call('cg_unshuffle_mask', _p(ws.e[i]), _p(ws.act[i]),
+                _p(ws.delta[i]), _p(self.shifts[i - 1]), self.nB, lay.lout,
+                lay.coutp, self.seg_size, LEAKY_ALPHA, st)
+    if self.input_grad is not None:
+      _run_conv(self.input_grad, st)
+
+  def jvp_forward(self):
+    st = _stream()
+    for d in self.jvp:
+      _run_conv(d, st)
+
+  def weight_grads(self, bias_rows):
+    """Accumulate dW (all nB samples), db (first bias_rows samples) and the
+    dense head gradients into params.grad (caller zeroed it)."""
+    st = _stream()
+    net, ws = self.ws.net, self.ws
+    for i, d in enumerate(self.wgrad):
+      _run_wgrad(d, st)
+      lay = net.layers[i]
+      if bias_rows > 0:
+        _lib.call('cg_colsum', _p(ws.delta[i + 1]),
+                  _p(net.params.grad_views[2 * i + 1]),
+                  bias_rows * lay.lout, lay.cout, lay.coutp, st)
+    last = net.layers[-1]
+    _lib.call('cg_dense1_wgrad', _p(ws.act[-1]), _p(self.coef),
+              _p(self.bias_coef), _p(net.params.grad_views[-2]),
+              _p(net.params.grad_views[-1]), self.nB, last.lout, last.cout,
+              last.coutp, self.seg_size, st)
+
+
+# ===========================================================================
+# Generator
+# ===========================================================================
+class GeneratorNet(object):
+  """Dense -> LeakyReLU -> reshape(w, nd) -> 5 x [Conv1DTranspose(k, s=2) ->
+  LayerNorm -> LeakyReLU] -> Dense(C) -> sigmoid  (calciumgan.py:22-103)."""
+
+  def __init__(self, hp, device, rng):
+    _require_gpu()
+    self.w0 = geo.validate_hparams(hp)
+    self.hp = hp
+    self.device = device
+    self.k = hp.kernel_size
+    self.pl = geo.same_padding_left(self.k, hp.strides)
+    self.nd = hp.noise_dim
+    self.layers = geo.generator_layers(hp)
+    self.C = hp.num_channels
+    self.Cp = geo.pitch(self.C)
+    self.L = hp.signal_shape[0]
+    self.layer_norm = bool(hp.layer_norm)
+    self.normalize = bool(hp.normalize)
+    nflat = self.w0 * self.nd
+    shapes = [(self.nd, nflat), (nflat,)]
+    init = [
+        glorot_uniform(rng, (self.nd, nflat), self.nd, nflat),
+        np.zeros(nflat, np.float32)
+    ]
+    self.idx_conv = []
+    for lay in self.layers:
+      self.idx_conv.append(len(shapes))
+      shapes += [(self.k, 1, lay.cout, lay.cin), (lay.cout,)]
+      init += [
+          glorot_uniform(rng, (self.k, 1, lay.cout, lay.cin),
+                         self.k * lay.cout, self.k * lay.cin),
+          np.zeros(lay.cout, np.float32)
+      ]
+      if self.layer_norm:
+        shapes += [(lay.cout,), (lay.cout,)]
+        init += [np.ones(lay.cout, np.float32), np.zeros(lay.cout, np.float32)]
+    self.idx_out = len(shapes)
+    shapes += [(self.C, self.C), (self.C,)]
+    init += [
+        glorot_uniform(rng, (self.C, self.C), self.C, self.C),
+        np.zeros(self.C, np.float32)
+    ]
+    self.params = FlatParams(shapes, device)
+    self.params.set_weights(init)
+    V = self.params.views
+    # packed operands
+    self.w_in = PackedOperand(V[0], [(0, 1, 0, nflat, 1)], self.nd, nflat,
+                              self.nd, self.nd, 1)
+    phases = _transpose_phases(self.k, self.pl)
+    self.fwd_offs = [o for _, o in phases]
+    self.w_fwd, self.w_dgrad = [], []
+    for lay, ic in zip(self.layers, self.idx_conv):
+      W = V[ic]
+      ci, co = lay.cin, lay.cout
+      ck = _ck_for(lay.cinp, 1, self.k // 2, lay.lin)
+      self.w_fwd.append(
+          PackedOperand(W, [(t0, -2, co * ci, 1, ci) for t0, _ in phases], ci,
+                        co, lay.cinp, ck, self.k // 2))
+      ck = _ck_for(lay.coutp, 2, self.k, lay.lin)
+      self.w_dgrad.append(
+          PackedOperand(W, [(0, 1, co * ci, ci, 1)], co, ci, lay.coutp, ck,
+                        self.k))
+    Wo = V[self.idx_out]
+    ck = _ck_for(self.Cp, 1, 1, self.L)
+    self.w_out = PackedOperand(Wo, [(0, 1, 0, self.C, 1)], self.C, self.C,
+                               self.Cp, ck, 1)
+    self.w_out_t = PackedOperand(Wo, [(0, 1, 0, 1, self.C)], self.C, self.C,
+                                 self.Cp, ck, 1)
+    self.repack()
+    self._ws = {}
+
+  def repack(self):
+    for op in [self.w_in, self.w_out, self.w_out_t] + self.w_fwd + self.w_dgrad:
+      op.repack()
+
+  def workspace(self, B):
+    ws = self._ws.get(B)
+    if ws is None:
+      ws = _GenWorkspace(self, B)
+      self._ws[B] = ws
+    return ws
+
+
+class _GenWorkspace(object):
+
+  def __init__(self, net, B):
+    dev = net.device
+    self.net, self.B = net, B
+    z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)
+    nd, w0 = net.nd, net.w0
+    V = net.params.views
+    self.z = z(B, 1, nd)
+    self.h = [z(B, w0, nd)] + [z(B, l.lout, l.coutp) for l in net.layers]
+    self.ypre = [None] + [z(B, l.lout, l.coutp) for l in net.layers]
+    self.mean = [None] + [z(B * l.lout, dt=torch.float32) for l in net.layers]
+    self.rstd = [None] + [z(B * l.lout, dt=torch.float32) for l in net.layers]
+    self.fake = z(B, net.L, net.Cp, dt=torch.float32)
+    # backward buffers
+    self.dz = z(B, net.L, net.Cp)
+    self.dh = [z(B, w0, nd)] + [z(B, l.lout, l.coutp) for l in net.layers]
+    self.dy = [z(B, 1, w0 * nd)] + [z(B, l.lout, l.coutp) for l in net.layers]
+    k = net.k
+    # ---- forward descriptors
+    self.f_in = _conv_desc(self.z, net.w_in.buf, self.h[0], B, 1, nd, 1, 1, 0, 1,
+                           w0 * nd, 1, w0 * nd, net.w_in.CK, bias=V[1],
+                           epilogue=_lib.EPI_LRELU)
+    self.f_conv = []
+    for i, (lay, ic) in enumerate(zip(net.layers, net.idx_conv)):
+      op = net.w_fwd[i]
+      dst = self.ypre[i + 1] if net.layer_norm else self.h[i + 1]
+      self.f_conv.append(
+          _conv_desc(self.h[i], op.buf, dst, B, lay.lin, lay.cinp, k // 2, 1,
+                     net.fwd_offs[0], lay.lin, lay.cout, lay.lout, lay.coutp,
+                     op.CK, y_stride=2, y_off=0, bias=V[ic + 1],
+                     epilogue=_lib.EPI_NONE
+                     if net.layer_norm else _lib.EPI_LRELU, nphase=2,
+                     w_phase_stride=op.elems,
+                     off_phase_step=net.fwd_offs[1] - net.fwd_offs[0],
+                     yoff_phase_step=1))
+    self.f_out = _conv_desc(
+        self.h[-1], net.w_out.buf, self.fake, B, net.L, net.Cp, 1, 1, 0, net.L,
+        net.C, net.L, net.Cp, net.w_out.CK, bias=V[net.idx_out + 1],
+        epilogue=_lib.EPI_SIGMOID if net.normalize else _lib.EPI_NONE,
+        out_f32=True)
+    # ---- backward descriptors
+    G = net.params.grad_views
+    self.b_out_dgrad = _conv_desc(self.dz, net.w_out_t.buf, self.dh[-1], B,
+                                  net.L, net.Cp, 1, 1, 0, net.L, net.C, net.L,
+                                  net.Cp, net.w_out_t.CK)
+    self.b_out_wgrad = _wgrad_desc(self.h[-1], self.dz, G[net.idx_out], B,
+                                   net.L, net.Cp, net.L, net.Cp, 1, 1, 0, net.C,
+                                   net.C)
+    self.b_dgrad, self.b_wgrad = [], []
+    for i, (lay, ic) in enumerate(zip(net.layers, net.idx_conv)):
+      op = net.w_dgrad[i]
+      self.b_dgrad.append(
+          _conv_desc(self.dy[i + 1], op.buf, self.dh[i], B, lay.lout, lay.coutp,
+                     k, 2, -net.pl, lay.lin, lay.cin, lay.lin, lay.cinp, op.CK))
+      self.b_wgrad.append(
+          _wgrad_desc(self.dy[i + 1], self.h[i], G[ic], B, lay.lout, lay.coutp,
+                      lay.lin, lay.cinp, k, 2, -net.pl, lay.cout, lay.cin))
+    self.b_in_wgrad = _wgrad_desc(self.z, self.dy[0], G[0], B, 1, nd, 1,
+                                  w0 * nd, 1, 1, 0, nd, w0 * nd)
+
+  def forward(self, z_f32):
+    """z (B, nd) f32 device -> self.fake (B, L, Cp) f32 (first C channels)."""
+    net = self.net
+    st = _stream()
+    _lib.call('cg_cast_pad', _p(z_f32), _p(self.z), self.B, net.nd, net.nd,
+              net.nd, st)
+    _run_conv(self.f_in, st)
+    V = net.params.views
+    for i, (lay, ic) in enumerate(zip(net.layers, net.idx_conv)):
+      _run_conv(self.f_conv[i], st)
+      if net.layer_norm:
+        _lib.call('cg_ln_lrelu_fwd', _p(self.ypre[i + 1]), _p(V[ic + 2]),
+                  _p(V[ic + 3]), _p(self.h[i + 1]), _p(self.mean[i + 1]),
+                  _p(self.rstd[i + 1]), self.B * lay.lout, lay.cout, lay.coutp,
+                  LN_EPS, LEAKY_ALPHA, st)
+    _run_conv(self.f_out, st)
+    return self.fake
+
+  def backward(self, dfake_f32):
+    """dfake (B, L, Cp) f32 = d loss / d fake -> accumulates every generator
+    gradient into params.grad (caller zeroed it)."""
+    net = self.net
+    st = _stream()
+    G = net.params.grad_views
+    V = net.params.views
+    rows = self.B * net.L
+    if net.normalize:
+      _lib.call('cg_sigmoid_bwd', _p(dfake_f32), _p(self.fake), _p(self.dz),
+                rows, net.C, net.Cp, net.Cp, st)
+    else:
+      _lib.call('cg_cast_pad', _p(dfake_f32), _p(self.dz), rows, net.C, net.Cp,
+                net.Cp, st)
+    _run_wgrad(self.b_out_wgrad, st)
+    _lib.call('cg_colsum', _p(self.dz), _p(G[net.idx_out + 1]), rows, net.C,
+              net.Cp, st)
+    _run_conv(self.b_out_dgrad, st)
+    for i in range(len(net.layers) - 1, -1, -1):
+      lay, ic = net.layers[i], net.idx_conv[i]
+      n = self.B * lay.lout
+      if net.layer_norm:
+        _lib.call('cg_ln_lrelu_bwd', _p(self.dh[i + 1]), _p(self.h[i + 1]),
+                  _p(self.ypre[i + 1]), _p(self.mean[i + 1]),
+                  _p(self.rstd[i + 1]), _p(V[ic + 2]), _p(self.dy[i + 1]),
+                  _p(G[ic + 2]), _p(G[ic + 3]), n, lay.cout, lay.coutp,
+                  LEAKY_ALPHA, st)
+      else:
+        _lib.call('cg_lrelu_bwd', _p(self.dh[i + 1]), _p(self.h[i + 1]),
+                  _p(self.dy[i + 1]), n * lay.coutp, LEAKY_ALPHA, st)
+      _run_wgrad(self.b_wgrad[i], st)
+      _lib.call('cg_colsum', _p(self.dy[i + 1]), _p(G[ic + 1]), n, lay.cout,
+                lay.coutp, st)
+      _run_conv(self.b_dgrad[i], st)
+    nflat = net.w0 * net.nd
+    _lib.call('cg_lrelu_bwd', _p(self.dh[0]), _p(self.h[0]), _p(self.dy[0]),
+              self.B * nflat, LEAKY_ALPHA, st)
+    _run_wgrad(self.b_in_wgrad, st)
+    _lib.call('cg_colsum', _p(self.dy[0]), _p(G[1]), self.B, nflat, nflat, st)
+
+
+def adam_update(params, step, lr, grad_scale=1.0, beta1=0.9, beta2=0.999,
+                eps=1e-7):
+  """tf.keras.optimizers.Adam dense update (gan/algorithms/optimizer.py:9,
+  :31-34); `step` is the 1-based iteration count."""
+  lr_t = lr * math.sqrt(1.0 - beta2**step) / (1.0 - beta1**step)
+  _lib.call('cg_adam', _p(params.data), _p(params.grad), _p(params.m),
+            _p(params.v), params.numel, lr_t, beta1, beta2, eps, grad_scale,
+            _stream())

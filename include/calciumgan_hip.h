@@ -1,0 +1,233 @@
+/* calciumgan_hip.h -- C ABI of the MI355X (gfx950) CalciumGAN hot-path kernels.
+ *
+ * Drop-in boundary: the reference has no FFI; the device ops
+ * it executes are whatever TensorFlow dispatches for the Keras layers named
+ * below.  Each entry point here replaces the device work of one reference
+ * call site (file:line relative to the reference repo) and is what a
+ * maintainer would bind (ctypes stub in INTEGRATION.md).
+ *
+ * Conventions for every function:
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless
+ *     the parameter is a `const cg_*_desc*` (host struct, read at call time);
+ *   - activations are channels-last bf16 [nB][L][Cp], Cp = channel pitch, a
+ *     multiple of 8; channels [C, Cp) are kept zero by every kernel;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are async,
+ *     re-entrant per stream, allocate nothing and keep no global state;
+ *   - the return value is a hipError_t (0 = success) or CG_EINVAL for a
+ *     shape the kernels do not support (nothing is launched in that case).
+ */
+#ifndef CALCIUMGAN_HIP_H_
+#define CALCIUMGAN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CG_EINVAL 100001
+#define CG_ABI_VERSION 1
+
+/* epilogue selectors of cg_swconv */
+#define CG_EPI_NONE 0     /* y = acc (+bias) */
+#define CG_EPI_LRELU 1    /* y = leaky_relu(acc + bias, alpha) */
+#define CG_EPI_MASK 2     /* y = acc * (mask_src > 0 ? 1 : alpha) */
+#define CG_EPI_SIGMOID 3  /* y = sigmoid(acc + bias) */
+
+int cg_abi_version(void);
+
+/* ---------------------------------------------------------------------------
+ * Sliding-window convolution as an implicit GEMM on MFMA (bf16 in, f32 acc).
+ *
+ *   y[b, y_stride*u + y_off, n] = epi( bias[n] +
+ *        sum_{tap<taps} sum_{c<Cx} xs[b, stride*u + off + tap, c] * Wl[tap][c][n] )
+ *
+ * for u in [0, Lu), n in [0, N); rows of xs outside [0, Lx) read as zero
+ * (TF 'same' padding) and xs = phase_shuffle(x, shifts[b / seg_size]) when
+ * `shifts` is non-NULL (reflect gather fused into the LDS staging).
+ * With nphase == 2 the launch computes two output phases z = 0,1 using
+ * w + z*w_phase_stride, off + z*off_phase_step, y_off + z*yoff_phase_step
+ * (the two 12-tap phases of a stride-2 transposed convolution).
+ *
+ * Replaces: layers.Conv1D fwd (gan/models/calciumgan.py:145-185) [stride 2,
+ * taps k]; its input-gradient / Conv1DTranspose fwd (gan/models/utils.py:86-89)
+ * [stride 1, taps k/2, two phases]; Conv1DTranspose input-gradient [stride 2];
+ * layers.Dense on the last axis (calciumgan.py:32,96) [taps 1].
+ *
+ * `w` is the packed operand produced by cg_pack_weights for the same
+ * (taps, Cx, CK).  Supported: stride in {1,2}; taps even when stride == 2;
+ * Cx % CK == 0, CK % 8 == 0, CK >= 32; Lu a power-of-two divisor or any
+ * multiple of the row tile (64 or 256).
+ * ------------------------------------------------------------------------- */
+typedef struct cg_conv_desc {
+  const void* x;        /* bf16 [nB][Lx][Cx] */
+  const void* w;        /* bf16 packed [ceil(N/64)*64][Kpack] per phase */
+  void* y;              /* bf16 or f32 [nB][Ly][Cy] */
+  const float* bias;    /* f32 [N] or NULL */
+  const void* mask_src; /* bf16, geometry of y; CG_EPI_MASK only */
+  const int* shifts;    /* int32 [ceil(nB/seg_size)] or NULL */
+  int nB, Lx, Cx, seg_size;
+  int taps, stride, off, Lu;
+  int N, Ly, Cy, y_stride, y_off;
+  int CK;
+  int epilogue, out_f32;
+  float alpha;          /* leaky slope */
+  int nphase;
+  long long w_phase_stride; /* elements */
+  int off_phase_step, yoff_phase_step;
+  int small_tile;       /* 0: 256-row tiles, 1: 64-row tiles */
+} cg_conv_desc;
+
+int cg_swconv(const cg_conv_desc* d, void* stream);
+/* elements (bf16) of one packed phase operand for (N, taps, Cx, CK) */
+long long cg_packed_elems(int N, int taps, int Cx, int CK);
+
+/* ---------------------------------------------------------------------------
+ * Pack an f32 master weight (TensorFlow layout, arbitrary strides) into the
+ * bf16 operand cg_swconv consumes:
+ *   Wl[tap][c][n] = src[(tap0 + tap*tap_step)*s_tap + c*s_c + n*s_n]
+ * for tap<taps, c<C_real, n<N_real; zero elsewhere (channel / row padding).
+ * Replaces nothing in the reference (TF keeps one layout); it is the
+ * MI355X-side operand preparation run after each optimizer update.
+ * ------------------------------------------------------------------------- */
+typedef struct cg_pack_desc {
+  const float* src;
+  void* dst; /* bf16, cg_packed_elems(N_real, taps, Cx, CK) elements */
+  int taps, tap0, tap_step;
+  long long s_tap, s_c, s_n;
+  int C_real, N_real, Cx, CK;
+} cg_pack_desc;
+int cg_pack_weights(const cg_pack_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Weight gradient of the sliding-window convolution (f32 accumulate, f32
+ * atomics into dw, which the caller zeroes):
+ *   dw[tap][cx][cg] += sum_{b,u} xs[b, stride*u + off + tap, cx] * g[b, u, cg]
+ * dw is dense f32 [taps][Cx_real][Cg_real].  Replaces the autodiff
+ * weight-gradient of Conv1D / Conv2DTranspose / Dense taken by
+ * tape.gradient in gan/algorithms/optimizer.py:31-34.
+ * Supported: (stride 2, even taps <= 24) or (stride 1, taps 1).
+ * ------------------------------------------------------------------------- */
+typedef struct cg_wgrad_desc {
+  const void* x;     /* bf16 [nB][Lx][Cx] */
+  const void* g;     /* bf16 [nB][Lu][Cg] */
+  float* dw;         /* f32 [taps][Cx_real][Cg_real] */
+  const int* shifts; /* phase shuffle applied to x rows, or NULL */
+  int nB, Lx, Cx, seg_size;
+  int Lu, Cg;
+  int taps, stride, off;
+  int Cx_real, Cg_real;
+  int nsplit;        /* 0 = choose */
+} cg_wgrad_desc;
+int cg_wgrad(const cg_wgrad_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * LayerNormalization(axis=-1, eps) + LeakyReLU, one wavefront per row.
+ * Replaces layers.LayerNormalization + activation_fn
+ * (calciumgan.py:44-46 etc.) and their autodiff backward.
+ * ------------------------------------------------------------------------- */
+int cg_ln_lrelu_fwd(const void* y_pre /*bf16 [rows][Cp]*/, const float* gamma,
+                    const float* beta, void* h /*bf16 [rows][Cp]*/,
+                    float* mean /*[rows] or NULL*/, float* rstd /*[rows] or NULL*/,
+                    long long rows, int C, int Cp, float eps, float alpha,
+                    void* stream);
+/* dy = d(loss)/d(y_pre); dgamma/dbeta accumulated with f32 atomics. */
+int cg_ln_lrelu_bwd(const void* dh /*bf16*/, const void* h /*bf16*/,
+                    const void* y_pre /*bf16*/, const float* mean,
+                    const float* rstd, const float* gamma, void* dy /*bf16*/,
+                    float* dgamma, float* dbeta, long long rows, int C, int Cp,
+                    float alpha, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Discriminator head: Flatten + Dense(1) (calciumgan.py:188-190).
+ * ------------------------------------------------------------------------- */
+/* h is bf16 [nB][Lt][Cp]; w is the f32 Keras kernel [Lt*C] (flatten index
+ * t*C + c, calciumgan.py:188), used rounded to bf16.
+ * out[b] = bias[0] + sum_{t,c<C} h[b][t][c] * bf16(w[t*C+c]) */
+int cg_dense1_fwd(const void* h, const float* w, const float* bias,
+                  float* out /*[nB]*/, int nB, int Lt, int C, int Cp,
+                  void* stream);
+/* delta[b][t][c] = coef[b / seg_size] * bf16(w[t*C+c]) * lrelu'(h[b][t][c]) */
+int cg_dense1_bwd(const float* w, const float* coef /*device [nseg]*/,
+                  const void* h, void* delta /*bf16*/, int nB, int Lt, int C,
+                  int Cp, int seg_size, float alpha, void* stream);
+/* dw[t*C+c] += sum_b coef[b / seg_size] * x[b][t][c];
+ * db[0] += sum_b bias_coef[b / seg_size]  (bias_coef may be NULL) */
+int cg_dense1_wgrad(const void* x /*bf16 [nB][Lt][Cp]*/, const float* coef,
+                    const float* bias_coef /*device [nseg]*/, float* dw,
+                    float* db, int nB, int Lt, int C, int Cp, int seg_size,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Backward of LeakyReLU + PhaseShuffle between discriminator layers:
+ *   delta[b][r][c] = lrelu'(h[b][r][c]) * sum_{t: src(t)=r} e[b][t][c]
+ * where src is the reflect gather of PhaseShuffle (calciumgan.py:117-138).
+ * ------------------------------------------------------------------------- */
+int cg_unshuffle_mask(const void* e /*bf16 [nB][w][Cp]*/, const void* h,
+                      void* delta, const int* shifts, int nB, int w, int Cp,
+                      int seg_size, float alpha, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * WGAN-GP elementwise / reduction pieces (gan/algorithms/wgan_gp.py).
+ * ------------------------------------------------------------------------- */
+/* x0[0:B]=bf16(real), x0[B:2B]=bf16(fake), x0[2B:3B]=bf16(alpha*real+(1-alpha)*fake)
+ * (wgan_gp.py:38-41); real f32 [B][L][Cr], fake f32 [B][L][Cf] (row pitches,
+ * C valid channels), x0 bf16 [3B][L][Cp]. */
+int cg_interp_pack(const float* real, const float* fake, const float* alpha,
+                   void* x0, int B, int L, int C, int Cr, int Cf, int Cp,
+                   void* stream);
+/* dst bf16 [rows][Cp] = src f32 [rows][Cs] (C valid channels), pad zero */
+int cg_cast_pad(const float* src, void* dst, long long rows, int C, int Cs,
+                int Cp, void* stream);
+/* norm[b] = ||g[b]||_2 over n elements (wgan_gp.py:49), g f32 [B][n] */
+int cg_rownorm(const float* g, float* norm, int B, long long n, void* stream);
+/* gp = mean((norm-1)^2) (wgan_gp.py:50); coef[b] = scale*2*(norm-1)/(B*norm) */
+int cg_gp_finalize(const float* norm, float* gp, float* coef, int B,
+                   float scale, void* stream);
+/* a0 bf16 [B][n] = coef[b] * g[b] */
+int cg_scale_rows(const float* g, const float* coef, void* a0, int B,
+                  long long n, void* stream);
+/* out[0] = -mean(d_out[0:B]) + mean(d_out[B:2B]) + penalty*gp[0]  (wgan_gp.py:58-61)
+ * out[1] = -mean(d_out[B:2B]) (generator_loss of the same fake batch) */
+int cg_critic_loss(const float* d_out, const float* gp, float penalty,
+                   float* out, int B, void* stream);
+/* out[0] = -mean(d_out[0:B])  (wgan_gp.py:19-20) */
+int cg_neg_mean(const float* d_out, float* out, int B, void* stream);
+
+/* out f32[C] += column sums of x bf16 [rows][Cp] (bias gradients) */
+int cg_colsum(const void* x, float* out, long long rows, int C, int Cp,
+              void* stream);
+/* dz = dfake * s * (1 - s)  (sigmoid backward; calciumgan.py:98-99) */
+int cg_sigmoid_bwd(const float* dfake /*f32 [rows][Cp]*/,
+                   const float* fake /*f32 [rows][Cf]*/,
+                   void* dz /*bf16 [rows][Cp]*/, long long rows, int C, int Cf,
+                   int Cp, void* stream);
+/* dpre = dh * lrelu'(h), all bf16 [n] */
+int cg_lrelu_bwd(const void* dh, const void* h, void* dpre, long long n,
+                 float alpha, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Keras Adam (gan/algorithms/optimizer.py:9; tf.keras.optimizers.Adam):
+ *   g = grad*grad_scale; m = b1*m + (1-b1)g; v = b2*v + (1-b2)g^2;
+ *   p -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
+ * ------------------------------------------------------------------------- */
+int cg_adam(float* p, const float* grad, float* m, float* v, long long n,
+            float lr_t, float beta1, float beta2, float eps, float grad_scale,
+            void* stream);
+
+/* ---------------------------------------------------------------------------
+ * GAN.metrics (gan/algorithms/gan.py:32-41, gan/utils/signals_metrics.py:9-28):
+ * out[0..3] += sum over rows of squared differences of per-row (min, max,
+ * mean, population-std) over channels of denormalised real vs fake; caller
+ * zeroes out and divides by rows.
+ * ------------------------------------------------------------------------- */
+int cg_signal_metrics(const float* real /*[rows][Cr]*/,
+                      const float* fake /*[rows][Cf]*/, float* out,
+                      long long rows, int C, int Cr, int Cf, float smin,
+                      float smax, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CALCIUMGAN_HIP_H_ */

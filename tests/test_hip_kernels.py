@@ -1,0 +1,497 @@
+"""GPU parity tests of the individual gfx950 kernels against the CPU oracle
+(torch autograd on the oracle's layer definitions).  All calls go through the
+C ABI (ctypes).  MFMA kernels are checked BIT-EXACTLY on small-integer data
+(exact in bf16, products/sums exact in f32); float kernels within a stated
+tolerance."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from calciumgan_amd import _lib
+from calciumgan_amd import geometry as geo
+from calciumgan_amd import nets
+
+pytestmark = pytest.mark.gpu
+
+import hip_utils as H  # noqa: E402
+
+BF16 = torch.bfloat16
+ALPHA = 0.3
+
+
+def _shuffle_batch(x, shifts, seg):
+  out = []
+  for b in range(x.shape[0]):
+    out.append(O.phase_shuffle(x[b:b + 1], int(shifts[b // seg])))
+  return torch.cat(out, 0)
+
+
+def test_pack_matches_numpy_layout():
+  rng = np.random.RandomState(0)
+  k, ci, co = 24, 10, 70
+  W = torch.tensor(rng.randn(k, ci, co).astype(np.float32)).to(H.DEV)
+  cx = geo.pitch(ci)
+  op = H.pack(W, [(0, 1, ci * co, co, 1)], ci, co, cx, cx, k)
+  H.sync()
+  exp = H.numpy_pack(
+      W.cpu().to(BF16).float().numpy(), cx, cx)
+  got = op.buf.float().cpu().numpy().reshape(exp.shape)
+  np.testing.assert_array_equal(got, exp)
+
+
+CONV_CASES = [
+    # nB, L, Ci, Co, k, seg, use_shift
+    (3, 128, 102, 64, 24, 1, True),
+    (2, 64, 16, 40, 24, 2, False),
+    (4, 16, 64, 72, 8, 2, True),
+    (2, 512, 64, 128, 24, 1, True),
+    (5, 32, 192, 200, 24, 5, False),
+    (96, 8, 128, 160, 24, 32, True),
+]
+
+
+@pytest.mark.parametrize('nB,L,Ci,Co,k,seg,use_shift', CONV_CASES)
+def test_conv_fwd_bitexact(nB, L, Ci, Co, k, seg, use_shift):
+  """Conv1D 'same' s=2 + bias + LeakyReLU with fused phase-shuffle gather
+  (calciumgan.py:145-150 + :117-138) on exact data."""
+  rng = np.random.RandomState(1)
+  x = H.int_tensor(rng, (nB, L, Ci))
+  W = H.int_tensor(rng, (k, Ci, Co), -2, 2, 0.5)
+  b = H.int_tensor(rng, (Co,), -4, 4)
+  nseg = (nB + seg - 1) // seg
+  shifts = rng.randint(-2, 3, size=nseg).astype(np.int32)
+  if not use_shift:
+    shifts[:] = 0
+  ref = O.leaky_relu(
+      O.conv1d_same(_shuffle_batch(x, shifts, seg), W, b, 2)).to(BF16).float()
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  Lo = L // 2
+  pl = geo.same_padding_left(k, 2)
+  Wd, bd = W.to(H.DEV), b.to(H.DEV)
+  ck = nets._ck_for(cip, 2, k, Lo)
+  op = H.pack(Wd, [(0, 1, Ci * Co, Co, 1)], Ci, Co, cip, ck, k)
+  xd = H.to_pitch(x, cip)
+  y = torch.full((nB, Lo, cop), 7.0, dtype=BF16, device=H.DEV)
+  sh = torch.tensor(shifts, device=H.DEV)
+  d = H.conv_desc(xd, op.buf, y, nB, L, cip, k, 2, -pl, Lo, Co, Lo, cop, ck,
+                  bias=bd, shifts=sh if use_shift else None, seg_size=seg,
+                  epilogue=_lib.EPI_LRELU)
+  H.run_conv(d)
+  H.sync()
+  got = y.float().cpu()
+  np.testing.assert_array_equal(got[:, :, :Co].numpy(), ref.numpy())
+  assert float(got[:, :, Co:].abs().max()) == 0.0 if cop > Co else True
+
+
+@pytest.mark.parametrize('small', [0, 1])
+def test_conv_fwd_both_tiles_agree(small):
+  rng = np.random.RandomState(2)
+  nB, L, Ci, Co, k = 2, 1024, 64, 64, 24
+  x = H.int_tensor(rng, (nB, L, Ci))
+  W = H.int_tensor(rng, (k, Ci, Co), -2, 2, 0.5)
+  ref = O.conv1d_same(x, W, None, 2)
+  op = H.pack(W.to(H.DEV), [(0, 1, Ci * Co, Co, 1)], Ci, Co, Ci, 64, k)
+  y = torch.zeros(nB, L // 2, Co, dtype=torch.float32, device=H.DEV)
+  d = H.conv_desc(H.to_pitch(x, Ci), op.buf, y, nB, L, Ci, k, 2, -11, L // 2,
+                  Co, L // 2, Co, 64, out_f32=True)
+  d.small_tile = small
+  H.run_conv(d)
+  H.sync()
+  np.testing.assert_array_equal(y.cpu().numpy(), ref.numpy())
+
+
+DGRAD_CASES = [
+    (3, 128, 102, 64, 24),
+    (2, 64, 16, 40, 24),
+    (4, 16, 64, 72, 8),
+    (2, 512, 64, 128, 24),
+    (48, 16, 96, 128, 24),
+]
+
+
+@pytest.mark.parametrize('nB,L,Ci,Co,k', DGRAD_CASES)
+def test_conv_dgrad_bitexact(nB, L, Ci, Co, k):
+  """Input-gradient of Conv1D 'same' s=2 == the two-phase transposed conv."""
+  rng = np.random.RandomState(3)
+  W = H.int_tensor(rng, (k, Ci, Co), -2, 2, 0.5)
+  dy = H.int_tensor(rng, (nB, L // 2, Co))
+  x = torch.zeros(nB, L, Ci, requires_grad=True)
+  (O.conv1d_same(x, W, None, 2) * dy).sum().backward()
+  ref = x.grad
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  pl = geo.same_padding_left(k, 2)
+  phases = nets._transpose_phases(k, pl)
+  ck = nets._ck_for(cop, 1, k // 2, L // 2)
+  op = H.pack(W.to(H.DEV), [(t0, -2, Ci * Co, 1, Co) for t0, _ in phases], Co,
+              Ci, cop, ck, k // 2)
+  y = torch.full((nB, L, cip), 3.0, dtype=torch.float32, device=H.DEV)
+  offs = [o for _, o in phases]
+  d = H.conv_desc(H.to_pitch(dy, cop), op.buf, y, nB, L // 2, cop, k // 2, 1,
+                  offs[0], L // 2, Ci, L, cip, ck, y_stride=2, y_off=0,
+                  out_f32=True, nphase=2, w_phase_stride=op.elems,
+                  off_phase_step=offs[1] - offs[0], yoff_phase_step=1)
+  H.run_conv(d)
+  H.sync()
+  got = y.cpu()
+  np.testing.assert_array_equal(got[:, :, :Ci].numpy(), ref.numpy())
+  if cip > Ci:
+    assert float(got[:, :, Ci:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('B,L,Ci,Co,k', [(2, 64, 32, 320, 24),
+                                          (3, 128, 128, 102, 24),
+                                          (2, 8, 32, 40, 24)])
+def test_conv_transpose_fwd_bitexact(B, L, Ci, Co, k):
+  """Conv1DTranspose (gan/models/utils.py:65-94) + bias."""
+  rng = np.random.RandomState(4)
+  x = H.int_tensor(rng, (B, L, Ci))
+  Wt = H.int_tensor(rng, (k, 1, Co, Ci), -2, 2, 0.5)
+  b = H.int_tensor(rng, (Co,), -4, 4)
+  ref = O.conv1d_transpose_same(x, Wt, b, 2)
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  pl = geo.same_padding_left(k, 2)
+  phases = nets._transpose_phases(k, pl)
+  offs = [o for _, o in phases]
+  ck = nets._ck_for(cip, 1, k // 2, L)
+  op = H.pack(Wt.to(H.DEV), [(t0, -2, Co * Ci, 1, Ci) for t0, _ in phases], Ci,
+              Co, cip, ck, k // 2)
+  y = torch.zeros(B, 2 * L, cop, dtype=torch.float32, device=H.DEV)
+  d = H.conv_desc(H.to_pitch(x, cip), op.buf, y, B, L, cip, k // 2, 1, offs[0],
+                  L, Co, 2 * L, cop, ck, y_stride=2, bias=b.to(H.DEV),
+                  out_f32=True, nphase=2, w_phase_stride=op.elems,
+                  off_phase_step=offs[1] - offs[0], yoff_phase_step=1)
+  H.run_conv(d)
+  H.sync()
+  np.testing.assert_array_equal(y.cpu()[:, :, :Co].numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize('B,L,Ci,Co,k', [(2, 64, 32, 320, 24),
+                                          (3, 128, 128, 102, 24)])
+def test_conv_transpose_dgrad_bitexact(B, L, Ci, Co, k):
+  rng = np.random.RandomState(5)
+  Wt = H.int_tensor(rng, (k, 1, Co, Ci), -2, 2, 0.5)
+  dy = H.int_tensor(rng, (B, 2 * L, Co))
+  x = torch.zeros(B, L, Ci, requires_grad=True)
+  (O.conv1d_transpose_same(x, Wt, None, 2) * dy).sum().backward()
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  ck = nets._ck_for(cop, 2, k, L)
+  op = H.pack(Wt.to(H.DEV), [(0, 1, Co * Ci, Ci, 1)], Co, Ci, cop, ck, k)
+  y = torch.zeros(B, L, cip, dtype=torch.float32, device=H.DEV)
+  d = H.conv_desc(H.to_pitch(dy, cop), op.buf, y, B, 2 * L, cop, k, 2, -11, L,
+                  Ci, L, cip, ck, out_f32=True)
+  H.run_conv(d)
+  H.sync()
+  np.testing.assert_array_equal(y.cpu()[:, :, :Ci].numpy(), x.grad.numpy())
+
+
+def test_dense_sigmoid_and_mask_epilogues():
+  rng = np.random.RandomState(6)
+  B, L, C = 2, 64, 102
+  x = torch.tensor(rng.randn(B, L, C).astype(np.float32)).to(BF16).float()
+  W = torch.tensor(rng.randn(C, C).astype(np.float32) * 0.1)
+  b = torch.tensor(rng.randn(C).astype(np.float32))
+  cp = geo.pitch(C)
+  op = H.pack(W.to(H.DEV), [(0, 1, 0, C, 1)], C, C, cp, cp, 1)
+  y = torch.zeros(B, L, cp, dtype=torch.float32, device=H.DEV)
+  d = H.conv_desc(H.to_pitch(x, cp), op.buf, y, B, L, cp, 1, 1, 0, L, C, L, cp,
+                  cp, bias=b.to(H.DEV), epilogue=_lib.EPI_SIGMOID, out_f32=True)
+  H.run_conv(d)
+  H.sync()
+  ref = torch.sigmoid(x @ W.to(BF16).float() + b)
+  np.testing.assert_allclose(
+      y.cpu()[:, :, :C].numpy(), ref.numpy(), rtol=2e-5, atol=2e-6)
+  assert float(y[:, :, C:].abs().max()) == 0.0
+  # mask epilogue, in place over the mask source
+  h = torch.tensor(rng.randn(B, L, C).astype(np.float32))
+  hd = H.to_pitch(h, cp)
+  d = H.conv_desc(H.to_pitch(x, cp), op.buf, hd, B, L, cp, 1, 1, 0, L, C, L, cp,
+                  cp, mask_src=hd, epilogue=_lib.EPI_MASK)
+  H.run_conv(d)
+  H.sync()
+  hq = h.to(BF16).float()
+  ref = (x @ W.to(BF16).float()) * torch.where(hq > 0, 1.0, ALPHA)
+  np.testing.assert_allclose(
+      hd.float().cpu()[:, :, :C].numpy(), ref.to(BF16).float().numpy(),
+      rtol=1e-2, atol=1e-2)
+
+
+WGRAD_CASES = [
+    (3, 128, 102, 64, 24, 1, True),
+    (2, 64, 16, 40, 24, 2, False),
+    (4, 16, 64, 72, 8, 2, True),
+    (6, 256, 64, 128, 24, 2, True),
+    (96, 8, 128, 160, 24, 32, True),
+]
+
+
+@pytest.mark.parametrize('nB,L,Ci,Co,k,seg,use_shift', WGRAD_CASES)
+def test_conv_wgrad_bitexact(nB, L, Ci, Co, k, seg, use_shift):
+  rng = np.random.RandomState(7)
+  x = H.int_tensor(rng, (nB, L, Ci), -2, 2)
+  dy = H.int_tensor(rng, (nB, L // 2, Co), -2, 2)
+  nseg = (nB + seg - 1) // seg
+  shifts = rng.randint(-2, 3, size=nseg).astype(np.int32)
+  if not use_shift:
+    shifts[:] = 0
+  W = torch.zeros(k, Ci, Co, requires_grad=True)
+  (O.conv1d_same(_shuffle_batch(x, shifts, seg), W, None, 2) *
+   dy).sum().backward()
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  dw = torch.zeros(k, Ci, Co, dtype=torch.float32, device=H.DEV)
+  sh = torch.tensor(shifts, device=H.DEV)
+  d = nets._wgrad_desc(H.to_pitch(x, cip), H.to_pitch(dy, cop), dw, nB, L, cip,
+                       L // 2, cop, k, 2, -geo.same_padding_left(k, 2), Ci, Co,
+                       shifts=sh if use_shift else None, seg_size=seg)
+  H.run_wgrad(d)
+  H.sync()
+  np.testing.assert_array_equal(dw.cpu().numpy(), W.grad.numpy())
+
+
+def test_conv_transpose_wgrad_bitexact():
+  rng = np.random.RandomState(8)
+  B, L, Ci, Co, k = 3, 64, 32, 72, 24
+  x = H.int_tensor(rng, (B, L, Ci), -2, 2)
+  dy = H.int_tensor(rng, (B, 2 * L, Co), -2, 2)
+  Wt = torch.zeros(k, 1, Co, Ci, requires_grad=True)
+  (O.conv1d_transpose_same(x, Wt, None, 2) * dy).sum().backward()
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  dw = torch.zeros(k, 1, Co, Ci, dtype=torch.float32, device=H.DEV)
+  d = nets._wgrad_desc(H.to_pitch(dy, cop), H.to_pitch(x, cip), dw, B, 2 * L,
+                       cop, L, cip, k, 2, -11, Co, Ci)
+  H.run_wgrad(d)
+  H.sync()
+  np.testing.assert_array_equal(dw.cpu().numpy(), Wt.grad.numpy())
+
+
+@pytest.mark.parametrize('B,L,Ci,Co', [(2, 512, 102, 102), (70, 1, 32, 256)])
+def test_dense_wgrad_bitexact(B, L, Ci, Co):
+  rng = np.random.RandomState(9)
+  x = H.int_tensor(rng, (B, L, Ci), -2, 2)
+  dy = H.int_tensor(rng, (B, L, Co), -2, 2)
+  ref = torch.einsum('blc,bld->cd', x, dy)
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  dw = torch.zeros(Ci, Co, dtype=torch.float32, device=H.DEV)
+  d = nets._wgrad_desc(H.to_pitch(x, cip), H.to_pitch(dy, cop), dw, B, L, cip,
+                       L, cop, 1, 1, 0, Ci, Co)
+  H.run_wgrad(d)
+  H.sync()
+  np.testing.assert_array_equal(dw.cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize('rows,C', [(300, 102), (64, 320), (17, 40)])
+def test_layernorm_lrelu_fwd_bwd(rows, C):
+  rng = np.random.RandomState(10)
+  cp = geo.pitch(C)
+  y = torch.tensor(rng.randn(1, rows, C).astype(np.float32) * 2 + 0.5)
+  gam = torch.tensor(rng.rand(C).astype(np.float32) + 0.5)
+  bet = torch.tensor(rng.randn(C).astype(np.float32) * 0.1)
+  dh = torch.tensor(rng.randn(1, rows, C).astype(np.float32))
+  yq = y.to(BF16).float().requires_grad_(True)
+  g_ = gam.clone().requires_grad_(True)
+  b_ = bet.clone().requires_grad_(True)
+  h_ref = O.leaky_relu(O.layer_norm(yq, g_, b_))
+  dhq = dh.to(BF16).float()
+  yd, dhd = H.to_pitch(y, cp), H.to_pitch(dh, cp)
+  h = torch.zeros(1, rows, cp, dtype=BF16, device=H.DEV)
+  mean = torch.zeros(rows, device=H.DEV)
+  rstd = torch.zeros(rows, device=H.DEV)
+  gd, bd = gam.to(H.DEV), bet.to(H.DEV)
+  _lib.call('cg_ln_lrelu_fwd', H.p(yd), H.p(gd), H.p(bd), H.p(h), H.p(mean),
+            H.p(rstd), rows, C, cp, 1e-3, ALPHA, H.stream())
+  H.sync()
+  np.testing.assert_allclose(
+      h.float().cpu()[0, :, :C].numpy(), h_ref.detach().numpy(), rtol=1e-2,
+      atol=1e-2)
+  if cp > C:
+    assert float(h[:, :, C:].float().abs().max()) == 0.0
+  # backward uses the bf16 h for the mask, as the product path does
+  hq = h.float().cpu()[:, :, :C]
+  mask = torch.where(hq > 0, 1.0, ALPHA)
+  (O.layer_norm(yq, g_, b_) * (dhq * mask)).sum().backward()
+  dy = torch.zeros(1, rows, cp, dtype=BF16, device=H.DEV)
+  dg = torch.zeros(C, device=H.DEV)
+  db = torch.zeros(C, device=H.DEV)
+  _lib.call('cg_ln_lrelu_bwd', H.p(dhd), H.p(h), H.p(yd), H.p(mean), H.p(rstd),
+            H.p(gd), H.p(dy), H.p(dg), H.p(db), rows, C, cp, ALPHA, H.stream())
+  H.sync()
+  np.testing.assert_allclose(
+      dy.float().cpu()[0, :, :C].numpy(), yq.grad[0].numpy(), rtol=2e-2,
+      atol=2e-2)
+  np.testing.assert_allclose(dg.cpu().numpy(), g_.grad.numpy(), rtol=1e-3,
+                             atol=1e-3)
+  np.testing.assert_allclose(db.cpu().numpy(), b_.grad.numpy(), rtol=1e-3,
+                             atol=1e-3)
+
+
+@pytest.mark.parametrize('w,m', [(16, 3), (64, 10), (8, 1)])
+def test_unshuffle_mask_is_adjoint_of_shuffle(w, m):
+  rng = np.random.RandomState(11)
+  nB, C, seg = 6, 40, 2
+  e = H.int_tensor(rng, (nB, w, C), -3, 3)
+  h = torch.tensor(rng.randn(nB, w, C).astype(np.float32))
+  shifts = rng.randint(-m, m + 1, size=3).astype(np.int32)
+  hx = h.to(BF16).float().requires_grad_(True)
+  # forward: pre -> lrelu -> shuffle; adjoint applied to e
+  pre = hx
+  out = _shuffle_batch(O.leaky_relu(pre), shifts, seg)
+  (out * e).sum().backward()
+  cp = geo.pitch(C)
+  ed = H.to_pitch(e, cp)
+  # mask source: the POST-activation (same sign as pre)
+  hd = H.to_pitch(O.leaky_relu(hx.detach()), cp)
+  delta = torch.zeros(nB, w, cp, dtype=BF16, device=H.DEV)
+  sh = torch.tensor(shifts, device=H.DEV)
+  _lib.call('cg_unshuffle_mask', H.p(ed), H.p(hd), H.p(delta), H.p(sh), nB, w,
+            cp, seg, ALPHA, H.stream())
+  H.sync()
+  np.testing.assert_allclose(
+      delta.float().cpu()[:, :, :C].numpy(),
+      hx.grad.to(BF16).float().numpy(), rtol=0, atol=0)
+
+
+def test_discriminator_head_kernels():
+  rng = np.random.RandomState(12)
+  nB, Lt, C, seg = 6, 8, 40, 2
+  cp = geo.pitch(C)
+  h = torch.tensor(rng.randn(nB, Lt, C).astype(np.float32)).to(BF16).float()
+  w = torch.tensor(rng.randn(Lt * C).astype(np.float32))
+  wq = w.to(BF16).float()
+  b = torch.tensor([0.25])
+  coef = torch.tensor([-0.5, 0.5, 1.0])
+  hd = H.to_pitch(h, cp)
+  wd, bd, cd = w.to(H.DEV), b.to(H.DEV), coef.to(H.DEV)
+  out = torch.zeros(nB, device=H.DEV)
+  _lib.call('cg_dense1_fwd', H.p(hd), H.p(wd), H.p(bd), H.p(out), nB, Lt, C, cp,
+            H.stream())
+  ref = h.reshape(nB, -1) @ wq + 0.25
+  H.sync()
+  np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5,
+                             atol=1e-5)
+  delta = torch.zeros(nB, Lt, cp, dtype=BF16, device=H.DEV)
+  _lib.call('cg_dense1_bwd', H.p(wd), H.p(cd), H.p(hd), H.p(delta), nB, Lt, C,
+            cp, seg, ALPHA, H.stream())
+  H.sync()
+  cb = coef.repeat_interleave(seg).reshape(nB, 1, 1)
+  refd = cb * wq.reshape(1, Lt, C) * torch.where(h > 0, 1.0, ALPHA)
+  np.testing.assert_array_equal(
+      delta.float().cpu()[:, :, :C].numpy(), refd.to(BF16).float().numpy())
+  dw = torch.zeros(Lt * C, device=H.DEV)
+  db = torch.zeros(1, device=H.DEV)
+  bc = torch.tensor([-0.5, 0.5, 0.0]).to(H.DEV)
+  _lib.call('cg_dense1_wgrad', H.p(hd), H.p(cd), H.p(bc), H.p(dw), H.p(db), nB,
+            Lt, C, cp, seg, H.stream())
+  H.sync()
+  refw = (cb * h).sum(0).reshape(-1)
+  np.testing.assert_allclose(dw.cpu().numpy(), refw.numpy(), rtol=1e-5,
+                             atol=1e-5)
+  np.testing.assert_allclose(db.cpu().numpy(), [0.0], atol=1e-6)
+
+
+def test_wgan_gp_elementwise_kernels():
+  rng = np.random.RandomState(13)
+  B, L, C = 4, 32, 102
+  cp = geo.pitch(C)
+  real = torch.tensor(rng.rand(B, L, C).astype(np.float32))
+  fake_p = torch.zeros(B, L, cp)
+  fake = torch.tensor(rng.rand(B, L, C).astype(np.float32))
+  fake_p[:, :, :C] = fake
+  alpha = torch.tensor(rng.rand(B).astype(np.float32))
+  x0 = torch.zeros(3 * B, L, cp, dtype=BF16, device=H.DEV)
+  _lib.call('cg_interp_pack', H.p(real.to(H.DEV)), H.p(fake_p.to(H.DEV)),
+            H.p(alpha.to(H.DEV)), H.p(x0), B, L, C, C, cp, cp, H.stream())
+  H.sync()
+  got = x0.float().cpu()
+  inter = O.interpolation(real, fake, alpha)
+  np.testing.assert_array_equal(got[:B, :, :C].numpy(),
+                                real.to(BF16).float().numpy())
+  np.testing.assert_array_equal(got[B:2 * B, :, :C].numpy(),
+                                fake.to(BF16).float().numpy())
+  np.testing.assert_allclose(got[2 * B:, :, :C].numpy(),
+                             inter.to(BF16).float().numpy(), rtol=8e-3)
+  assert float(got[:, :, C:].abs().max()) == 0.0
+  # penalty norm / finalize / scale
+  g = torch.tensor(rng.randn(B, L * cp).astype(np.float32) * 0.05)
+  gd = g.to(H.DEV)
+  norm = torch.zeros(B, device=H.DEV)
+  gp = torch.zeros(1, device=H.DEV)
+  coef = torch.zeros(B, device=H.DEV)
+  _lib.call('cg_rownorm', H.p(gd), H.p(norm), B, L * cp, H.stream())
+  _lib.call('cg_gp_finalize', H.p(norm), H.p(gp), H.p(coef), B, 10.0, H.stream())
+  a0 = torch.zeros(B, L * cp, dtype=BF16, device=H.DEV)
+  _lib.call('cg_scale_rows', H.p(gd), H.p(coef), H.p(a0), B, L * cp, H.stream())
+  H.sync()
+  gr = g.clone().requires_grad_(True)
+  nr = gr.pow(2).sum(1).sqrt()
+  gpr = ((nr - 1)**2).mean()
+  (10.0 * gpr).backward()
+  np.testing.assert_allclose(norm.cpu().numpy(), nr.detach().numpy(), rtol=1e-5)
+  np.testing.assert_allclose(gp.cpu().numpy(), [gpr.item()], rtol=1e-5)
+  np.testing.assert_allclose(a0.float().cpu().numpy(), gr.grad.numpy(),
+                             rtol=1e-2, atol=1e-6)
+  # losses
+  d_out = torch.tensor(rng.randn(3 * B).astype(np.float32)).to(H.DEV)
+  out = torch.zeros(2, device=H.DEV)
+  _lib.call('cg_critic_loss', H.p(d_out), H.p(gp), 10.0, H.p(out), B, H.stream())
+  H.sync()
+  do = d_out.cpu()
+  exp0 = -do[:B].mean() + do[B:2 * B].mean() + 10.0 * gp.cpu()[0]
+  np.testing.assert_allclose(out.cpu().numpy(),
+                             [exp0.item(), -do[B:2 * B].mean().item()],
+                             rtol=1e-5)
+
+
+def test_adam_colsum_sigmoid_lrelu_metrics():
+  rng = np.random.RandomState(14)
+  n = 10007
+  p0 = torch.tensor(rng.randn(n).astype(np.float32))
+  g = torch.tensor(rng.randn(n).astype(np.float32))
+  m0 = torch.tensor(rng.randn(n).astype(np.float32) * 0.1)
+  v0 = torch.tensor(rng.rand(n).astype(np.float32) * 0.1)
+  pr, mr, vr = p0.double(), m0.double(), v0.double()
+  O.keras_adam(pr, g.double() * 0.5, mr, vr, 3, 1e-3)
+  pd, gd, md, vd = (t.clone().to(H.DEV) for t in (p0, g, m0, v0))
+  import math
+  lr_t = 1e-3 * math.sqrt(1 - 0.999**3) / (1 - 0.9**3)
+  _lib.call('cg_adam', H.p(pd), H.p(gd), H.p(md), H.p(vd), n, lr_t, 0.9, 0.999,
+            1e-7, 0.5, H.stream())
+  H.sync()
+  np.testing.assert_allclose(pd.cpu().numpy(), pr.float().numpy(), rtol=1e-6,
+                             atol=1e-7)
+  np.testing.assert_allclose(md.cpu().numpy(), mr.float().numpy(), rtol=1e-6)
+  np.testing.assert_allclose(vd.cpu().numpy(), vr.float().numpy(), rtol=1e-6)
+  # colsum
+  rows, C = 1000, 102
+  cp = geo.pitch(C)
+  x = H.int_tensor(rng, (1, rows, C), -3, 3)
+  out = torch.zeros(C, device=H.DEV)
+  _lib.call('cg_colsum', H.p(H.to_pitch(x, cp)), H.p(out), rows, C, cp,
+            H.stream())
+  H.sync()
+  np.testing.assert_array_equal(out.cpu().numpy(), x[0].sum(0).numpy())
+  # sigmoid bwd
+  fake = torch.tensor(rng.rand(1, rows, C).astype(np.float32))
+  dfake = torch.zeros(1, rows, cp)
+  dfake[:, :, :C] = torch.tensor(rng.randn(1, rows, C).astype(np.float32))
+  dz = torch.zeros(1, rows, cp, dtype=BF16, device=H.DEV)
+  _lib.call('cg_sigmoid_bwd', H.p(dfake.to(H.DEV)), H.p(fake.to(H.DEV)),
+            H.p(dz), rows, C, C, cp, H.stream())
+  H.sync()
+  ref = dfake[:, :, :C] * fake * (1 - fake)
+  np.testing.assert_allclose(dz.float().cpu()[:, :, :C].numpy(),
+                             ref.to(BF16).float().numpy(), rtol=8e-3,
+                             atol=1e-7)
+  # metrics
+  real = torch.tensor(rng.rand(3, 50, C).astype(np.float32))
+  fk = torch.tensor(rng.rand(3, 50, C).astype(np.float32))
+  buf = torch.zeros(4, device=H.DEV)
+  _lib.call('cg_signal_metrics', H.p(real.to(H.DEV)), H.p(fk.to(H.DEV)),
+            H.p(buf), 150, C, C, C, -1.0, 3.0, H.stream())
+  H.sync()
+  refm = O.signal_metrics(real, fk, -1.0, 3.0, True)
+  got = buf.cpu().numpy() / 150
+  exp = [refm['signals_metrics/' + k].item() for k in ('min', 'max', 'mean',
+                                                        'std')]
+  np.testing.assert_allclose(got, exp, rtol=1e-4)
