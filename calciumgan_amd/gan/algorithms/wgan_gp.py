@@ -93,8 +93,9 @@ class WGAN_GP(GAN):
               nets._p(st['loss'][slot]), B, s)
     return fake
 
-  def _train_discriminator(self, real, r=None, slot=0):
+  def _train_discriminator(self, inputs, r=None, slot=0):
     """wgan_gp.py:64-80."""
+    real = self._to_device(inputs)
     B = real.shape[0]
     st = self._get_state(B)
     net_d = self.discriminator.net
@@ -125,8 +126,9 @@ class WGAN_GP(GAN):
     self.dis_optimizer.update(self.discriminator, self._sync.grad_scale)
     return st['loss'][slot, 0], st['gp'][slot]
 
-  def _train_generator(self, real, r=None):
+  def _train_generator(self, inputs, r=None):
     """wgan_gp.py:22-36."""
+    real = self._to_device(inputs)
     B = real.shape[0]
     st = self._get_state(B)
     net_g, net_d = self.generator.net, self.discriminator.net

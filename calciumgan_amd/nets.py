@@ -145,6 +145,7 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
                seg_size=1, epilogue=_lib.EPI_NONE, out_f32=False, nphase=1,
                w_phase_stride=0, off_phase_step=0, yoff_phase_step=0):
   d = ConvDesc()
+  d._keep = (x, w, y, bias, mask_src, shifts)  # pointers below borrow these
   d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
   d.bias = bias.data_ptr() if bias is not None else None
   d.mask_src = mask_src.data_ptr() if mask_src is not None else None
@@ -167,6 +168,7 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
 def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,
                 Cg_real, shifts=None, seg_size=1):
   d = WgradDesc()
+  d._keep = (x, g, dw, shifts)  # pointers below borrow these
   d.x, d.g, d.dw = x.data_ptr(), g.data_ptr(), dw.data_ptr()
   d.shifts = shifts.data_ptr() if shifts is not None else None
   d.nB, d.Lx, d.Cx, d.seg_size = nB, Lx, Cx, seg_size

@@ -303,7 +303,7 @@ def test_layernorm_lrelu_fwd_bwd(rows, C):
             H.p(rstd), rows, C, cp, 1e-3, ALPHA, H.stream())
   H.sync()
   np.testing.assert_allclose(
-      h.float().cpu()[0, :, :C].numpy(), h_ref.detach().numpy(), rtol=1e-2,
+      h.float().cpu()[0, :, :C].numpy(), h_ref.detach()[0].numpy(), rtol=1e-2,
       atol=1e-2)
   if cp > C:
     assert float(h[:, :, C:].float().abs().max()) == 0.0
@@ -400,8 +400,9 @@ def test_wgan_gp_elementwise_kernels():
   fake_p[:, :, :C] = fake
   alpha = torch.tensor(rng.rand(B).astype(np.float32))
   x0 = torch.zeros(3 * B, L, cp, dtype=BF16, device=H.DEV)
-  _lib.call('cg_interp_pack', H.p(real.to(H.DEV)), H.p(fake_p.to(H.DEV)),
-            H.p(alpha.to(H.DEV)), H.p(x0), B, L, C, C, cp, cp, H.stream())
+  real_d, fake_d, alpha_d = real.to(H.DEV), fake_p.to(H.DEV), alpha.to(H.DEV)
+  _lib.call('cg_interp_pack', H.p(real_d), H.p(fake_d), H.p(alpha_d), H.p(x0),
+            B, L, C, C, cp, cp, H.stream())
   H.sync()
   got = x0.float().cpu()
   inter = O.interpolation(real, fake, alpha)
@@ -460,15 +461,17 @@ def test_adam_colsum_sigmoid_lrelu_metrics():
   H.sync()
   np.testing.assert_allclose(pd.cpu().numpy(), pr.float().numpy(), rtol=1e-6,
                              atol=1e-7)
-  np.testing.assert_allclose(md.cpu().numpy(), mr.float().numpy(), rtol=1e-6)
-  np.testing.assert_allclose(vd.cpu().numpy(), vr.float().numpy(), rtol=1e-6)
+  np.testing.assert_allclose(md.cpu().numpy(), mr.float().numpy(), rtol=1e-6,
+                             atol=1e-7)
+  np.testing.assert_allclose(vd.cpu().numpy(), vr.float().numpy(), rtol=1e-6,
+                             atol=1e-7)
   # colsum
   rows, C = 1000, 102
   cp = geo.pitch(C)
   x = H.int_tensor(rng, (1, rows, C), -3, 3)
   out = torch.zeros(C, device=H.DEV)
-  _lib.call('cg_colsum', H.p(H.to_pitch(x, cp)), H.p(out), rows, C, cp,
-            H.stream())
+  xd = H.to_pitch(x, cp)
+  _lib.call('cg_colsum', H.p(xd), H.p(out), rows, C, cp, H.stream())
   H.sync()
   np.testing.assert_array_equal(out.cpu().numpy(), x[0].sum(0).numpy())
   # sigmoid bwd
@@ -476,8 +479,9 @@ def test_adam_colsum_sigmoid_lrelu_metrics():
   dfake = torch.zeros(1, rows, cp)
   dfake[:, :, :C] = torch.tensor(rng.randn(1, rows, C).astype(np.float32))
   dz = torch.zeros(1, rows, cp, dtype=BF16, device=H.DEV)
-  _lib.call('cg_sigmoid_bwd', H.p(dfake.to(H.DEV)), H.p(fake.to(H.DEV)),
-            H.p(dz), rows, C, C, cp, H.stream())
+  dfake_d, fake_d = dfake.to(H.DEV), fake.to(H.DEV)
+  _lib.call('cg_sigmoid_bwd', H.p(dfake_d), H.p(fake_d), H.p(dz), rows, C, C,
+            cp, H.stream())
   H.sync()
   ref = dfake[:, :, :C] * fake * (1 - fake)
   np.testing.assert_allclose(dz.float().cpu()[:, :, :C].numpy(),
@@ -487,8 +491,9 @@ def test_adam_colsum_sigmoid_lrelu_metrics():
   real = torch.tensor(rng.rand(3, 50, C).astype(np.float32))
   fk = torch.tensor(rng.rand(3, 50, C).astype(np.float32))
   buf = torch.zeros(4, device=H.DEV)
-  _lib.call('cg_signal_metrics', H.p(real.to(H.DEV)), H.p(fk.to(H.DEV)),
-            H.p(buf), 150, C, C, C, -1.0, 3.0, H.stream())
+  real_d, fk_d = real.to(H.DEV), fk.to(H.DEV)
+  _lib.call('cg_signal_metrics', H.p(real_d), H.p(fk_d), H.p(buf), 150, C, C, C,
+            -1.0, 3.0, H.stream())
   H.sync()
   refm = O.signal_metrics(real, fk, -1.0, 3.0, True)
   got = buf.cpu().numpy() / 150
