@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Headline benchmark: WGAN-GP training samples/sec of the CalciumGAN 1-D conv
+stack at BASELINE.json configs[1] (DG sl2048, 102 neurons, batch 128 per GPU,
+num_units 64, k 24, s 2, layer_norm, n_critic 5), bf16 MFMA / f32 accumulate.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one WGAN_GP.train() = 5 critic updates + 1 generator update on one
+batch (reference gan/algorithms/wgan_gp.py:82-95).  Inputs are resident in HBM
+before the timed region; timing is barrier + synchronize on both sides, MAX
+over ranks; rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MFMA_BF16_PEAK = 2.5e15  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_hparams(L, C, U, m):
+  from types import SimpleNamespace
+  return SimpleNamespace(
+      signal_shape=(L, C), sequence_length=L, num_channels=C, num_neurons=C,
+      num_units=U, kernel_size=24, strides=2, noise_dim=32, noise_shape=(32,),
+      m=m, layer_norm=True, batch_norm=False, normalize=True,
+      activation='leakyrelu', gradient_penalty=10.0, n_critic=5,
+      learning_rate=1e-4, signals_min=0.0, signals_max=1.0, conv2d=False,
+      mixed_precision=False, model='calciumgan', algorithm='wgan-gp', verbose=0)
+
+
+def algorithmic_flops(hp):
+  """FLOPs per training sample of one train(): 8 F_G + 52 F_D - 10 F_D1
+  (SURVEY 3.3 / BASELINE.md 2), split by kernel family."""
+  from calciumgan_amd import geometry as geo
+  k = hp.kernel_size
+  g_layers, d_layers = geo.generator_layers(hp), geo.discriminator_layers(hp)
+  w0 = g_layers[0].lin
+  macs_g = hp.noise_dim * w0 * hp.noise_dim
+  macs_g += sum(l.lin * k * l.cin * l.cout for l in g_layers)
+  macs_g += hp.signal_shape[0] * hp.num_channels * hp.num_channels
+  macs_d = sum(l.lout * k * l.cin * l.cout for l in d_layers)
+  macs_d += d_layers[-1].lout * d_layers[-1].cout
+  f_g, f_d = 2.0 * macs_g, 2.0 * macs_d
+  f_d1 = 2.0 * d_layers[0].lout * k * d_layers[0].cin * d_layers[0].cout
+  n = hp.n_critic
+  swconv = n * (f_g + 7 * f_d - 2 * f_d1) + 2 * f_g + 2 * f_d
+  wgrad = n * 3 * f_d + f_g
+  total = (n + 3) * f_g + (10 * n + 2) * f_d - 2 * n * f_d1
+  assert abs(total - swconv - wgrad) < 1e-3 * total
+  return dict(total=total, swconv=swconv, wgrad=wgrad, f_g=f_g, f_d=f_d)
+
+
+def cpu_baseline(hp, batch, steps):
+  """The oracle (CPU restatement, NOT TensorFlow) timed on this box's host
+  cores on a bounded sample of the same workload."""
+  import oracle as O
+  ohp = O.make_hparams(hp.signal_shape[0], hp.num_channels, hp.num_units,
+                       kernel_size=hp.kernel_size, m=hp.m)
+  rng = np.random.RandomState(0)
+  gan = O.OracleGAN(ohp, O.init_generator(ohp, rng),
+                    O.init_discriminator(ohp, rng))
+  real = rng.uniform(0, 1, (batch,) + hp.signal_shape).astype(np.float32)
+  gan.train(real, O.draw_randomness(ohp, batch, 0))  # warm-up
+  t0 = time.time()
+  for i in range(steps):
+    gan.train(real, O.draw_randomness(ohp, batch, i + 1))
+  dt = time.time() - t0
+  return dict(
+      value=batch * steps / dt, unit='samples/s',
+      cores=torch.get_num_threads(), kind='port',
+      sample='same shapes (L={}, C={}, U={}), batch {} of the benchmark batch, '
+      '1 warm-up + {} timed train() steps of the torch-CPU f32 oracle '
+      '(restatement of the reference graph, not TensorFlow)'.format(
+          hp.signal_shape[0], hp.num_channels, hp.num_units, batch, steps))
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--batch', type=int, default=128, help='per-GPU batch')
+  ap.add_argument('--seq_len', type=int, default=2048)
+  ap.add_argument('--neurons', type=int, default=102)
+  ap.add_argument('--num_units', type=int, default=64)
+  ap.add_argument('--m', type=int, default=10)
+  ap.add_argument('--no_cpu_baseline', action='store_true')
+  ap.add_argument('--cpu_batch', type=int, default=8)
+  ap.add_argument('--cpu_steps', type=int, default=3)
+  ap.add_argument('--no_kernel_timing', action='store_true')
+  args = ap.parse_args()
+
+  from calciumgan_amd import nets, parallel
+  world = parallel.env_world()
+  if world > 1:
+    parallel.init_process_group('nccl')
+  else:
+    torch.cuda.set_device(0)
+  rank = parallel.rank()
+  if world != args.gpus and rank == 0:
+    print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world),
+          file=sys.stderr)
+
+  from calciumgan_amd.data import dg
+  from calciumgan_amd.gan.algorithms import get_algorithm
+  from calciumgan_amd.gan.models import get_models
+
+  hp = make_hparams(args.seq_len, args.neurons, args.num_units, args.m)
+  gen, dis = get_models(hp, None)
+  gan = get_algorithm(hp, gen, dis, None)
+
+  B = args.batch
+  data = dg.make_dataset(args.neurons, args.seq_len, num_segments=B,
+                         seed=1234 + rank)
+  real = torch.from_numpy(data['signals']).to(gan.device).contiguous()
+
+  def barrier():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    gan.train(real)
+  records = []
+  if not args.no_kernel_timing:
+    nets.set_profile(records)
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    out = gan.train(real)
+  barrier()
+  dt = time.perf_counter() - t0
+  nets.set_profile(None)
+  losses = [float(out[0]), float(out[1]), float(out[2])]
+
+  t = torch.tensor([dt], dtype=torch.float64, device=gan.device)
+  if world > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  dt = float(t.item())
+
+  if rank == 0:
+    fl = algorithmic_flops(hp)
+    value = world * B * args.steps / dt
+    roofline = None
+    fam = {}
+    for name, s, e in records:
+      d = fam.setdefault(name, [0.0, 0])
+      d[0] += s.elapsed_time(e) * 1e-3
+      d[1] += 1
+    if 'swconv' in fam:
+      sec, cnt = fam['swconv']
+      flops = fl['swconv'] * B * args.steps
+      roofline = dict(
+          kernel='swconv_kernel (all MFMA conv / dgrad / dense launches)',
+          bound='mfma', achieved=flops / sec / 1e12,
+          peak=MFMA_BF16_PEAK / 1e12, unit='TFLOP/s',
+          frac=flops / sec / MFMA_BF16_PEAK, traffic=None,
+          launches_per_step=cnt / args.steps,
+          avg_launch_us=sec / cnt * 1e6,
+          flop_per_launch=flops / cnt,
+          share_of_step=sec / dt)
+      if 'wgrad' in fam:
+        wsec, wcnt = fam['wgrad']
+        wfl = fl['wgrad'] * B * args.steps
+        roofline['wgrad_kernel'] = dict(
+            achieved=wfl / wsec / 1e12, frac=wfl / wsec / MFMA_BF16_PEAK,
+            launches_per_step=wcnt / args.steps, avg_launch_us=wsec / wcnt * 1e6,
+            share_of_step=wsec / dt)
+    line = {
+        'metric': 'training samples/sec (seq_len={}, n_critic={})'.format(
+            args.seq_len, hp.n_critic),
+        'value': value,
+        'unit': 'samples/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'bf16',
+        'data': 'synthetic',
+        'config': {
+            'workload': 'cfg2: dichotomised-Gaussian sl{} calcium signals, {} '
+                        'neurons, batch {}/GPU, calciumgan num_units {} k 24 s 2 '
+                        'm {} layer_norm, wgan-gp n_critic 5 lambda 10, Keras '
+                        'Adam 1e-4'.format(args.seq_len, args.neurons, B,
+                                           args.num_units, args.m),
+            'global_batch': world * B,
+            'seq_len': args.seq_len,
+            'parallelism': 'dp{}'.format(world),
+        },
+        'gflop_per_sample_step': fl['total'] / 1e9,
+        'model_tflops': value * fl['total'] / 1e12,
+        'final_losses': losses,
+        'roofline': roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      line['cpu_baseline'] = cpu_baseline(hp, args.cpu_batch, args.cpu_steps)
+    else:
+      line['cpu_baseline'] = None
+    print(json.dumps(line))
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

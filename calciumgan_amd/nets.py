@@ -179,12 +179,35 @@ def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,
   return d
 
 
+# Optional per-launch timing of the two MFMA kernel families (bench.py's
+# roofline leg): a list that receives (family, start_event, end_event), events
+# recorded on the stream the kernel is launched on.
+_PROFILE = None
+
+
+def set_profile(records):
+  global _PROFILE
+  _PROFILE = records
+
+
+def _timed(name, family, d, st):
+  if _PROFILE is None:
+    _lib.call(name, ctypes.byref(d), st)
+    return
+  s = torch.cuda.Event(enable_timing=True)
+  e = torch.cuda.Event(enable_timing=True)
+  s.record()
+  _lib.call(name, ctypes.byref(d), st)
+  e.record()
+  _PROFILE.append((family, s, e))
+
+
 def _run_conv(d, st):
-  _lib.call('cg_swconv', ctypes.byref(d), st)
+  _timed('cg_swconv', 'swconv', d, st)
 
 
 def _run_wgrad(d, st):
-  _lib.call('cg_wgrad', ctypes.byref(d), st)
+  _timed('cg_wgrad', 'wgrad', d, st)
 
 
 def glorot_uniform(rng, shape, fan_in, fan_out):
