@@ -1,0 +1,135 @@
+"""CPU tests: the C-ABI library builds for gfx950, loads, and exports every
+symbol include/calciumgan_hip.h declares; host-side shape logic; the registry /
+error surface; loud failure without a device (no CPU fallback)."""
+import os
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from calciumgan_amd import _lib
+from calciumgan_amd import build as cg_build
+from calciumgan_amd import geometry as geo
+from calciumgan_amd import nets
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'calciumgan_hip.h')
+
+
+def _declared():
+  src = open(HEADER).read()
+  src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+  return sorted(set(re.findall(r'\b(?:int|long long)\s+(cg_\w+)\s*\(', src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+  cg_build.build(verbose=False)
+  lib = _lib.load()
+  names = _declared()
+  assert len(names) >= 20
+  for n in names:
+    assert hasattr(lib, n), 'missing export ' + n
+    assert n in _lib.SIGNATURES, 'no ctypes signature for ' + n
+  assert sorted(_lib.SIGNATURES) == names
+  assert lib.cg_abi_version() == 1
+
+
+def test_packed_elems_host_formula():
+  lib = _lib.load()
+  # N rows padded to 64, K padded to 16 groups of 8 per channel chunk
+  assert lib.cg_packed_elems(64, 24, 104, 104) == 64 * 320 * 8
+  assert lib.cg_packed_elems(102, 1, 104, 104) == 128 * 16 * 8
+  assert lib.cg_packed_elems(320, 12, 256, 64) == 320 * 4 * 96 * 8
+  assert lib.cg_packed_elems(64, 24, 100, 50) == -1  # CK not multiple of 8
+
+
+def test_no_cpu_fallback_without_device():
+  if torch.cuda.is_available():
+    pytest.skip('device present')
+  hp = O.make_hparams(64, 6, 8)
+  with pytest.raises(RuntimeError):
+    nets.DiscriminatorNet(hp, torch.device('cpu'), np.random.RandomState(0))
+  from calciumgan_amd.gan.models import get_models
+  hp.verbose = 0
+  with pytest.raises(RuntimeError):
+    get_models(hp, None)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+  monkeypatch.setattr(_lib, '_lib', None)
+  monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libcalciumgan_hip.so')
+  with pytest.raises(_lib.HipLibraryError):
+    _lib.load()
+
+
+def test_registries_mirror_reference_contract(capsys):
+  from calciumgan_amd.gan.algorithms import registry as areg
+  from calciumgan_amd.gan.models import registry as mreg
+  import calciumgan_amd.gan.algorithms  # noqa: F401  (registers)
+  import calciumgan_amd.gan.models  # noqa: F401
+  assert 'calciumgan' in mreg._MODELS
+  assert set(areg._ALGORITHMS) >= {'gan', 'wgan-gp'}
+  # unknown names print and exit (gan/models/registry.py:17-19)
+  with pytest.raises(SystemExit):
+    mreg.get_models(SimpleNamespace(model='wavegan'), None)
+  assert 'not found' in capsys.readouterr().out
+  with pytest.raises(SystemExit):
+    areg.get_algorithm(SimpleNamespace(algorithm='lswgan'), None, None, None)
+
+
+def test_layer_tables_match_survey_appendix_b():
+  hp = O.make_hparams(2048, 102, 64)
+  d = geo.discriminator_layers(hp)
+  assert [(l.cin, l.cout, l.lin, l.lout) for l in d] == [
+      (102, 64, 2048, 1024), (64, 128, 1024, 512), (128, 192, 512, 256),
+      (192, 256, 256, 128), (256, 320, 128, 64)]
+  g = geo.generator_layers(hp)
+  assert [(l.cin, l.cout, l.lin, l.lout) for l in g] == [
+      (32, 320, 64, 128), (320, 256, 128, 256), (256, 192, 256, 512),
+      (192, 128, 512, 1024), (128, 102, 1024, 2048)]
+  assert d[0].cinp == 104 and g[-1].coutp == 104
+  assert geo.pitch(6) == 32 and geo.pitch(320) == 320 and geo.pitch(130) == 160
+
+
+def test_validate_hparams_errors():
+  with pytest.raises(ValueError):  # calciumgan.py:17-18
+    geo.validate_hparams(O.make_hparams(100, 4, 8))
+  with pytest.raises(ValueError):
+    geo.validate_hparams(O.make_hparams(96, 4, 8))  # L/32 = 3 unsupported
+  with pytest.raises(ValueError):
+    geo.validate_hparams(O.make_hparams(64, 4, 8, strides=3))
+  with pytest.raises(ValueError):
+    geo.validate_hparams(O.make_hparams(64, 4, 8, m=4))  # reflect pad >= len
+  assert geo.validate_hparams(O.make_hparams(2048, 102, 64, m=10)) == 64
+
+
+@pytest.mark.parametrize('k', [24, 8, 2])
+def test_transpose_phase_walk_equals_conv_transpose(k):
+  """Host-side phase/tap/offset spec used for dgrad + Conv1DTranspose, checked
+  in numpy against the oracle: out[2u+p] = sum_jj x[u+off_p+jj] W[tap0_p-2jj]."""
+  rng = np.random.RandomState(0)
+  L, Ci, Co = 8, 3, 4
+  x = rng.randn(1, L, Ci)
+  Wt = rng.randn(k, 1, Co, Ci)
+  ref = O.conv1d_transpose_same(
+      torch.tensor(x), torch.tensor(Wt), None, 2).numpy()[0]
+  pl = geo.same_padding_left(k, 2)
+  out = np.zeros((2 * L, Co))
+  for p, (tap0, off) in enumerate(nets._transpose_phases(k, pl)):
+    for u in range(L):
+      for jj in range(k // 2):
+        i = u + off + jj
+        if 0 <= i < L:
+          out[2 * u + p] += Wt[tap0 - 2 * jj, 0] @ x[0, i]
+  np.testing.assert_allclose(out, ref, atol=1e-12)
+
+
+def test_ck_choice_fits_lds():
+  for cx, stride, taps, lu in [(104, 2, 24, 1024), (64, 2, 24, 512),
+                               (320, 1, 12, 64), (256, 2, 24, 64),
+                               (32, 1, 1, 1), (104, 1, 1, 2048)]:
+    ck = nets._ck_for(cx, stride, taps, lu)
+    assert cx % ck == 0 and ck % 8 == 0 and ck >= 32

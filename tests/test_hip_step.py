@@ -271,3 +271,47 @@ def test_weights_roundtrip_and_param_counts():
   gen.set_weights([a * 0 + 1 for a in w])
   assert all(float(a.min()) == 1.0 for a in gen.get_weights())
   assert len(dis.get_weights()) == 12
+
+
+def test_hip_step_against_committed_golden():
+  """Replays tests/golden/wgan_gp_step_tiny.npz (f32 oracle outputs on fixed
+  weights / inputs / randomness) through the HIP path.  Tolerances: forward
+  values 3e-2 relative (bf16 storage vs f32 golden), whole-gradient norm 2e-2,
+  cosine >= 0.985 (see _check_grads for why element-wise bounds follow the
+  bf16 noise floor)."""
+  import os
+  from calciumgan_amd.gan.algorithms import get_algorithm
+  from calciumgan_amd.gan.models import get_models
+  d = np.load(os.path.join(os.path.dirname(__file__), 'golden',
+                           'wgan_gp_step_tiny.npz'))
+  hp = O.make_hparams(64, 6, 8, m=2)
+  hp.verbose = 0
+  gen, dis = get_models(hp, None)
+  gan = get_algorithm(hp, gen, dis, None)
+  gen.set_weights([d['gw%02d' % i] for i in range(24)])
+  dis.set_weights([d['dw%02d' % i] for i in range(12)])
+  r = dict(z=d['z'], alpha=d['alpha'], shifts_real=d['shifts_real'],
+           shifts_fake=d['shifts_fake'], shifts_inter=d['shifts_inter'])
+  # keep the optimizer from moving the weights before the generator check
+  gan.dis_optimizer.learning_rate = 0.0
+  loss, gp = gan._train_discriminator(d['real'], r, slot=0)
+  torch.cuda.synchronize()
+  st = gan._get_state(4)
+  np.testing.assert_allclose(st['norm'].cpu().numpy(), d['norm'], rtol=3e-2)
+  np.testing.assert_allclose(float(gp), d['gp'], rtol=3e-2)
+  np.testing.assert_allclose(float(loss), d['dis_loss'], rtol=3e-2)
+  fake = st['gws'].fake[:, :, :6].cpu().numpy()
+  np.testing.assert_allclose(fake, d['fake'], atol=2e-2)
+  gh = _flat(dis.net.params.grad_views)
+  gr = _flat([d['dgrad%02d' % i] for i in range(12)])
+  assert abs(np.linalg.norm(gh) / np.linalg.norm(gr) - 1) < 2e-2
+  assert gh @ gr / (np.linalg.norm(gh) * np.linalg.norm(gr)) > 0.985
+  gan.gen_optimizer.learning_rate = 0.0
+  gl, _ = gan._train_generator(d['real'],
+                               dict(z=d['gen_z'], shifts=d['gen_shifts']))
+  torch.cuda.synchronize()
+  np.testing.assert_allclose(float(gl), d['gen_loss'], rtol=3e-2, atol=3e-3)
+  gh = _flat(gen.net.params.grad_views)
+  gr = _flat([d['ggrad%02d' % i] for i in range(24)])
+  assert abs(np.linalg.norm(gh) / np.linalg.norm(gr) - 1) < 2e-2
+  assert gh @ gr / (np.linalg.norm(gh) * np.linalg.norm(gr)) > 0.985
