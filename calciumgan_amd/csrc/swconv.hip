@@ -14,7 +14,7 @@
 //     once per tile and reused by up to taps/R output rows (no im2col).
 //   * stride-2 windows are de-interleaved by row parity while staging, so every
 //     tap becomes a stride-1 walk over one parity region: MFMA A fragments are
-//     single 16-byte ds_read_b128 with an odd 16-B-slot row pitch (bank-conflict
+//     single 16-byte ds_read_b128 with a 2*odd 16-B-slot row pitch (bank-conflict
 //     free), and the channel chunk CK bounds LDS use.
 //   * the weight operand is pre-packed (cg_pack_weights) in exactly the K order
 //     the kernel walks, so a B stage is a contiguous 256-B-per-row copy.
@@ -41,13 +41,19 @@ struct ConvArgs {
   int pitchA, S, log2S, nseg, WR, ldsA_elems;
   int epilogue, out_f32;
   float alpha;
+  float inv_c8;
   long long w_phase_stride;
   int off_phase_step, yoff_phase_step;
 };
 
-constexpr int kPitchB = 136;          // 128 + 8 bf16: 17 16-B slots per row
+// LDS row pitches are 2*odd 16-byte slots: with the MFMA operand map (lane ->
+// row l&15, k-group l>>4) and ds_read_b128's lane groups {0-3,12-15,20-27},
+// {4-11,16-19,28-31} (+32), the 8 lanes of k-group g land on the even slots
+// and the 8 lanes of k-group g+1 (next 16-B chunk) on the odd slots: no bank
+// conflicts.  (An odd pitch gives 2-way conflicts on every fragment read.)
+constexpr int kPitchB = 144;          // 128 + 16 bf16: 18 slots per row
 constexpr int kScrPitch = 68;         // fp32 epilogue scratch pitch
-constexpr int kLdsBBytes = 64 * kPitchB * 2;
+constexpr int kLdsBBytes = 2 * 64 * kPitchB * 2;  // double-buffered
 constexpr int kScratchBytes = 4 * 16 * kScrPitch * 4;
 
 template <int R, int MT>
@@ -86,49 +92,94 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int totalA = R * regionRows * a.c8;
+  // B staging: thread -> rows (tid >> 4) + 16*i, i = 0..3, 16-byte group
+  // f = tid & 15 (named registers, not arrays: keeps the prefetch out of scratch)
+  const uint16_t* bsrc = wp + (long long)(n0 + (tid >> 4)) * a.Kpack + (tid & 15) * 8;
+  const long long bstep = 16 * a.Kpack;
+  const int bdst = (tid >> 4) * kPitchB + (tid & 15) * 8;
+  constexpr int kBStepDst = 16 * kPitchB;
+  constexpr int kBufB = 64 * kPitchB;  // elements per B buffer
+  uint4 b0, b1, b2, b3;
+#define CG_LOAD_B(koff)                                                     \
+  do {                                                                      \
+    b0 = *reinterpret_cast<const uint4*>(bsrc + (koff));                    \
+    b1 = *reinterpret_cast<const uint4*>(bsrc + (koff) + bstep);            \
+    b2 = *reinterpret_cast<const uint4*>(bsrc + (koff) + 2 * bstep);        \
+    b3 = *reinterpret_cast<const uint4*>(bsrc + (koff) + 3 * bstep);        \
+  } while (0)
+#define CG_STORE_B(buf)                                                     \
+  do {                                                                      \
+    *reinterpret_cast<uint4*>((buf) + bdst) = b0;                           \
+    *reinterpret_cast<uint4*>((buf) + bdst + kBStepDst) = b1;               \
+    *reinterpret_cast<uint4*>((buf) + bdst + 2 * kBStepDst) = b2;           \
+    *reinterpret_cast<uint4*>((buf) + bdst + 3 * kBStepDst) = b3;           \
+  } while (0)
 
   for (int cc = 0; cc < a.nchunks; ++cc) {
+    // first B stage of this chunk: issue the loads before touching LDS so
+    // their latency overlaps the A staging below
+    CG_LOAD_B((long long)cc * a.Fp * 8);
     __syncthreads();  // previous chunk's fragment reads are done
     // ---- stage the source window of this channel chunk ------------------
-    for (int idx = tid; idx < totalA; idx += 256) {
-      const int row = idx / a.c8;
-      const int q8 = idx - row * a.c8;
-      const int rho = row / regionRows;
-      const int rem = row - rho * regionRows;
-      const int seg = rem / a.WR;
-      const int wr = rem - seg * a.WR;
-      const int mseg = m0 + seg * a.S;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (mseg < a.M) {
-        const int b = mseg / a.Lu;
-        const int u0 = mseg - b * a.Lu;
-        int srow = R * u0 + off + R * wr + rho;
-        if (srow >= 0 && srow < a.Lx) {
-          if (a.shifts) srow = shuffle_src(srow, a.shifts[b / a.seg_size], a.Lx);
-          const uint16_t* src =
-              a.x + ((long long)b * a.Lx + srow) * a.Cx + cc * a.CK + q8 * 8;
-          v = *reinterpret_cast<const uint4*>(src);
+    if (a.nseg == 1) {
+      // fast path (per-sample length >= tile): one sample per tile, no
+      // per-piece integer division (row = idx / c8 through an exact float
+      // reciprocal; everything else is wave-uniform)
+      const int b = m0 / a.Lu;
+      const int u0 = m0 - b * a.Lu;
+      const bool valid = m0 < a.M;
+      const int sft = (a.shifts && valid) ? a.shifts[b / a.seg_size] : 0;
+      const uint16_t* xb = a.x + (long long)b * a.Lx * a.Cx + cc * a.CK;
+      const int srow0 = R * u0 + off;
+      for (int idx = tid; idx < totalA; idx += 256) {
+        const int row = __float2int_rz(((float)idx + 0.5f) * a.inv_c8);
+        const int q8 = idx - row * a.c8;
+        const int rho = (R == 2 && row >= a.WR) ? 1 : 0;
+        const int wr = row - rho * a.WR;
+        int srow = srow0 + R * wr + rho;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (valid && srow >= 0 && srow < a.Lx) {
+          if (a.shifts) srow = shuffle_src(srow, sft, a.Lx);
+          v = *reinterpret_cast<const uint4*>(xb + (long long)srow * a.Cx +
+                                              q8 * 8);
         }
+        *reinterpret_cast<uint4*>(ldsA + row * a.pitchA + q8 * 8) = v;
       }
-      *reinterpret_cast<uint4*>(ldsA + row * a.pitchA + q8 * 8) = v;
+    } else {
+      for (int idx = tid; idx < totalA; idx += 256) {
+        const int row = idx / a.c8;
+        const int q8 = idx - row * a.c8;
+        const int rho = row / regionRows;
+        const int rem = row - rho * regionRows;
+        const int seg = rem / a.WR;
+        const int wr = rem - seg * a.WR;
+        const int mseg = m0 + seg * a.S;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (mseg < a.M) {
+          const int b = mseg / a.Lu;
+          const int u0 = mseg - b * a.Lu;
+          int srow = R * u0 + off + R * wr + rho;
+          if (srow >= 0 && srow < a.Lx) {
+            if (a.shifts)
+              srow = shuffle_src(srow, a.shifts[b / a.seg_size], a.Lx);
+            const uint16_t* src =
+                a.x + ((long long)b * a.Lx + srow) * a.Cx + cc * a.CK + q8 * 8;
+            v = *reinterpret_cast<const uint4*>(src);
+          }
+        }
+        *reinterpret_cast<uint4*>(ldsA + row * a.pitchA + q8 * 8) = v;
+      }
     }
+    CG_STORE_B(ldsB);
+    __syncthreads();
 
     // per-lane flattened K position inside the chunk: f = 4*kstep + g
     int tap = 0, q8l = g;  // c8 >= 4
     for (int s = 0; s < a.nstages; ++s) {
-      if (s > 0) __syncthreads();  // previous stage's B reads are done
-      // ---- stage 64 x 128 of the packed weight operand ------------------
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i;
-        const int n = idx >> 4;
-        const int f = idx & 15;
-        const uint16_t* src = wp + (long long)(n0 + n) * a.Kpack +
-                              ((long long)cc * a.Fp + 16 * s + f) * 8;
-        *reinterpret_cast<uint4*>(ldsB + n * kPitchB + f * 8) =
-            *reinterpret_cast<const uint4*>(src);
-      }
-      __syncthreads();
+      const uint16_t* curB = ldsB + (s & 1) * kBufB;
+      const bool more = s + 1 < a.nstages;
+      if (more)  // prefetch the next 64 x 128 weight stage into registers
+        CG_LOAD_B(((long long)cc * a.Fp + 16 * (s + 1)) * 8);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int t = tap < a.taps ? tap : a.taps - 1;  // padded K: B is zero
@@ -141,7 +192,7 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
           bfrag[nt] = *reinterpret_cast<const bf16x8*>(
-              ldsB + (nt * 16 + r16) * kPitchB + (4 * ks + g) * 8);
+              curB + (nt * 16 + r16) * kPitchB + (4 * ks + g) * 8);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const bf16x8 afrag =
@@ -156,6 +207,11 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
           q8l -= a.c8;
           ++tap;
         }
+      }
+      if (more) {
+        uint16_t* nxtB = ldsB + ((s + 1) & 1) * kBufB;
+        CG_STORE_B(nxtB);
+        __syncthreads();
       }
     }
   }
@@ -347,10 +403,11 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   a.N = d->N; a.Ly = d->Ly; a.Cy = d->Cy; a.y_stride = d->y_stride;
   a.y_off = d->y_off;
   a.CK = d->CK; a.c8 = d->CK / 8; a.nchunks = d->Cx / d->CK;
+  a.inv_c8 = 1.0f / (float)a.c8;
   a.Fp = (d->taps * a.c8 + 15) / 16 * 16;
   a.nstages = a.Fp / 16;
   a.Kpack = (long long)a.nchunks * a.Fp * 8;
-  a.pitchA = d->CK + ((a.c8 & 1) ? 16 : 8);
+  a.pitchA = d->CK + 8 * ((6 - (a.c8 & 3)) & 3);  // slots == 2 (mod 4)
   a.S = S; a.log2S = ilog2(S); a.nseg = TM / S;
   a.WR = S + d->taps / R - 1;
   a.ldsA_elems = R * a.nseg * a.WR * a.pitchA;

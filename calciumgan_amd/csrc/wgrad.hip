@@ -47,15 +47,66 @@ __device__ __forceinline__ bf16x8 join(s16x4 lo, s16x4 hi) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// R: source stride (1|2).  TPW: taps per wave.  ROWSPLIT: taps == 1, the waves
-// split the staged rows (TT = 256) instead of the taps (TT = 64).
+// MFMA work of one staged tile: every wave reads its transposed fragments from
+// the row-major LDS images and accumulates its taps.
 template <int R, int TPW, bool ROWSPLIT>
+__device__ __forceinline__ void wgrad_compute(const WgradArgs& a,
+                                              const uint16_t* ldsX,
+                                              const uint16_t* ldsG,
+                                              int regionRows, int wave, int g4,
+                                              int q, int p,
+                                              f32x4 (&acc)[TPW][2][4]) {
+  constexpr int KSTEPS = ROWSPLIT ? 1 : 2;
+#pragma unroll
+  for (int kstep = 0; kstep < KSTEPS; ++kstep) {
+    const int rbase = ROWSPLIT ? wave * 32 : kstep * 32;
+    // tile rows of this lane's two transposed reads (k = 8*g4 + 4*h + q')
+    const int i0 = rbase + 4 * g4 + q;
+    const int i1 = i0 + 16;
+    bf16x8 bfrag[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      bfrag[nt] = join(tr_read(ldsG + i0 * kPitchG + nt * 16 + 4 * p),
+                       tr_read(ldsG + i1 * kPitchG + nt * 16 + 4 * p));
+    const int x0 = ((i0 >> a.log2S) * a.WR + (i0 & (a.S - 1))) * kPitchX;
+    const int x1 = ((i1 >> a.log2S) * a.WR + (i1 & (a.S - 1))) * kPitchX;
+#pragma unroll
+    for (int s = 0; s < TPW; ++s) {
+      const int tap = ROWSPLIT ? 0 : wave + 8 * s;
+      if (tap < a.taps) {  // wave-uniform
+        int toff;
+        if (R == 2)
+          toff = ((tap & 1) * regionRows + (tap >> 1)) * kPitchX;
+        else
+          toff = tap * kPitchX;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const bf16x8 afrag =
+              join(tr_read(ldsX + x0 + toff + mt * 16 + 4 * p),
+                   tr_read(ldsX + x1 + toff + mt * 16 + 4 * p));
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[s][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                afrag, bfrag[nt], acc[s][mt][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// R: source stride (1|2).  TPW: taps per wave.  ROWSPLIT: taps == 1, the waves
+// split the staged rows (TT = 256) instead of the taps (TT = 64).  PIPE: one
+// sample per tile (nseg == 1): tiles are double-buffered in LDS and the next
+// tile's global loads are issued before the current tile's MFMAs.
+template <int R, int TPW, bool ROWSPLIT, bool PIPE>
 __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TT = ROWSPLIT ? 256 : 64;
+  constexpr int NG = TT * 8 / 512;  // g pieces per thread (1 or 4)
   const int regionRows = a.nseg * a.WR;
-  uint16_t* ldsX = reinterpret_cast<uint16_t*>(smem);
-  uint16_t* ldsG = ldsX + R * regionRows * kPitchX;
+  const int bufX = R * regionRows * kPitchX;  // elements
+  const int bufG = TT * kPitchG;
+  uint16_t* lds = reinterpret_cast<uint16_t*>(smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -78,78 +129,125 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   const int totalX = R * regionRows * 4;
   const int totalG = TT * 8;
 
-  for (int tile = blockIdx.z; tile < a.ntiles; tile += gridDim.z) {
-    const int m0 = tile * TT;
-    __syncthreads();
-    for (int idx = tid; idx < totalX; idx += 512) {
-      const int row = idx >> 2;
-      const int q8 = idx & 3;
-      const int rho = row / regionRows;
-      const int rem = row - rho * regionRows;
-      const int seg = rem / a.WR;
-      const int wr = rem - seg * a.WR;
-      const int mseg = m0 + seg * a.S;
-      const int c = cx0 + q8 * 8;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (mseg < a.M && c < a.Cx) {
-        const int b = mseg / a.Lu;
-        const int u0 = mseg - b * a.Lu;
-        int srow = R * u0 + a.off + R * wr + rho;
-        if (srow >= 0 && srow < a.Lx) {
-          if (a.shifts) srow = shuffle_src(srow, a.shifts[b / a.seg_size], a.Lx);
-          v = *reinterpret_cast<const uint4*>(
-              a.x + ((long long)b * a.Lx + srow) * a.Cx + c);
+  if (PIPE) {
+    // per-thread piece coordinates (fixed across tiles)
+    const int xq8 = tid & 3;
+    const int xc = cx0 + xq8 * 8;
+    const int xrowA = tid >> 2;          // piece 0
+    const int xrowB = (tid + 512) >> 2;  // piece 1 (if tid + 512 < totalX)
+    const bool hasB = tid + 512 < totalX;
+    const int rhoA = (R == 2 && xrowA >= a.WR) ? 1 : 0;
+    const int rhoB = (R == 2 && xrowB >= a.WR) ? 1 : 0;
+    const int dA = R * (xrowA - rhoA * a.WR) + rhoA;  // source row delta
+    const int dB = R * (xrowB - rhoB * a.WR) + rhoB;
+    const int gq8 = tid & 7;
+    const int gc = cg0 + gq8 * 8;
+    const int grow = tid >> 3;  // + 64 * j
+    uint4 xa, xb, gr[NG];
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+
+    auto load_tile = [&](int tile) {
+      const int m0 = tile * TT;
+      const int b = m0 / a.Lu;
+      const int u0 = m0 - b * a.Lu;
+      const int sft = a.shifts ? a.shifts[b / a.seg_size] : 0;
+      const uint16_t* xbase = a.x + (long long)b * a.Lx * a.Cx + xc;
+      const int srow0 = R * u0 + a.off;
+      xa = zero;
+      xb = zero;
+      if (xc < a.Cx) {
+        int sr = srow0 + dA;
+        if (sr >= 0 && sr < a.Lx) {
+          if (a.shifts) sr = shuffle_src(sr, sft, a.Lx);
+          xa = *reinterpret_cast<const uint4*>(xbase + (long long)sr * a.Cx);
+        }
+        sr = srow0 + dB;
+        if (hasB && sr >= 0 && sr < a.Lx) {
+          if (a.shifts) sr = shuffle_src(sr, sft, a.Lx);
+          xb = *reinterpret_cast<const uint4*>(xbase + (long long)sr * a.Cx);
         }
       }
-      *reinterpret_cast<uint4*>(ldsX + row * kPitchX + q8 * 8) = v;
-    }
-    for (int idx = tid; idx < totalG; idx += 512) {
-      const int row = idx >> 3;
-      const int q8 = idx & 7;
-      const int m = m0 + row;
-      const int c = cg0 + q8 * 8;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (m < a.M && c < a.Cg)
-        v = *reinterpret_cast<const uint4*>(a.g + (long long)m * a.Cg + c);
-      *reinterpret_cast<uint4*>(ldsG + row * kPitchG + q8 * 8) = v;
+#pragma unroll
+      for (int j = 0; j < NG; ++j) {
+        const int m = m0 + grow + 64 * j;
+        gr[j] = zero;
+        if (m < a.M && gc < a.Cg)
+          gr[j] = *reinterpret_cast<const uint4*>(a.g + (long long)m * a.Cg + gc);
+      }
+    };
+    auto store_tile = [&](uint16_t* base) {
+      uint16_t* lx = base;
+      uint16_t* lg = base + bufX;
+      *reinterpret_cast<uint4*>(lx + xrowA * kPitchX + xq8 * 8) = xa;
+      if (hasB) *reinterpret_cast<uint4*>(lx + xrowB * kPitchX + xq8 * 8) = xb;
+#pragma unroll
+      for (int j = 0; j < NG; ++j)
+        *reinterpret_cast<uint4*>(lg + (grow + 64 * j) * kPitchG + gq8 * 8) =
+            gr[j];
+    };
+
+    const int stride = gridDim.z;
+    int tile = blockIdx.z;
+    int cur = 0;
+    if (tile < a.ntiles) {
+      load_tile(tile);
+      store_tile(lds);
     }
     __syncthreads();
-
-    constexpr int KSTEPS = ROWSPLIT ? 1 : 2;
-#pragma unroll
-    for (int kstep = 0; kstep < KSTEPS; ++kstep) {
-      const int rbase = ROWSPLIT ? wave * 32 : kstep * 32;
-      // tile rows of this lane's two transposed reads (k = 8*g4 + 4*h + q')
-      const int i0 = rbase + 4 * g4 + q;
-      const int i1 = i0 + 16;
-      bf16x8 bfrag[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        bfrag[nt] = join(tr_read(ldsG + i0 * kPitchG + nt * 16 + 4 * p),
-                         tr_read(ldsG + i1 * kPitchG + nt * 16 + 4 * p));
-      const int x0 = ((i0 >> a.log2S) * a.WR + (i0 & (a.S - 1))) * kPitchX;
-      const int x1 = ((i1 >> a.log2S) * a.WR + (i1 & (a.S - 1))) * kPitchX;
-#pragma unroll
-      for (int s = 0; s < TPW; ++s) {
-        const int tap = ROWSPLIT ? 0 : wave + 8 * s;
-        if (tap < a.taps) {  // wave-uniform
-          int toff;
-          if (R == 2)
-            toff = ((tap & 1) * regionRows + (tap >> 1)) * kPitchX;
-          else
-            toff = tap * kPitchX;
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const bf16x8 afrag =
-                join(tr_read(ldsX + x0 + toff + mt * 16 + 4 * p),
-                     tr_read(ldsX + x1 + toff + mt * 16 + 4 * p));
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-              acc[s][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  afrag, bfrag[nt], acc[s][mt][nt], 0, 0, 0);
+    for (; tile < a.ntiles; tile += stride) {
+      const bool more = tile + stride < a.ntiles;
+      if (more) load_tile(tile + stride);
+      const uint16_t* base = lds + cur * (bufX + bufG);
+      wgrad_compute<R, TPW, ROWSPLIT>(a, base, base + bufX, regionRows, wave, g4,
+                                      q, p, acc);
+      if (more) {
+        store_tile(lds + (cur ^ 1) * (bufX + bufG));
+        __syncthreads();
+        cur ^= 1;
+      }
+    }
+  } else {
+    uint16_t* ldsX = lds;
+    uint16_t* ldsG = lds + bufX;
+    for (int tile = blockIdx.z; tile < a.ntiles; tile += gridDim.z) {
+      const int m0 = tile * TT;
+      __syncthreads();
+      for (int idx = tid; idx < totalX; idx += 512) {
+        const int row = idx >> 2;
+        const int q8 = idx & 3;
+        const int rho = row / regionRows;
+        const int rem = row - rho * regionRows;
+        const int seg = rem / a.WR;
+        const int wr = rem - seg * a.WR;
+        const int mseg = m0 + seg * a.S;
+        const int c = cx0 + q8 * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (mseg < a.M && c < a.Cx) {
+          const int b = mseg / a.Lu;
+          const int u0 = mseg - b * a.Lu;
+          int srow = R * u0 + a.off + R * wr + rho;
+          if (srow >= 0 && srow < a.Lx) {
+            if (a.shifts)
+              srow = shuffle_src(srow, a.shifts[b / a.seg_size], a.Lx);
+            v = *reinterpret_cast<const uint4*>(
+                a.x + ((long long)b * a.Lx + srow) * a.Cx + c);
           }
         }
+        *reinterpret_cast<uint4*>(ldsX + row * kPitchX + q8 * 8) = v;
       }
+      for (int idx = tid; idx < totalG; idx += 512) {
+        const int row = idx >> 3;
+        const int q8 = idx & 7;
+        const int m = m0 + row;
+        const int c = cg0 + q8 * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (m < a.M && c < a.Cg)
+          v = *reinterpret_cast<const uint4*>(a.g + (long long)m * a.Cg + c);
+        *reinterpret_cast<uint4*>(ldsG + row * kPitchG + q8 * 8) = v;
+      }
+      __syncthreads();
+      wgrad_compute<R, TPW, ROWSPLIT>(a, ldsX, ldsG, regionRows, wave, g4, q, p,
+                                      acc);
     }
   }
 
@@ -178,19 +276,26 @@ inline int ilog2(int v) {
   return l;
 }
 
-template <int R, int TPW, bool ROWSPLIT>
-int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+template <int R, int TPW, bool ROWSPLIT, bool PIPE>
+int launch_wgrad1(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&wgrad_kernel<R, TPW, ROWSPLIT>),
+        reinterpret_cast<const void*>(&wgrad_kernel<R, TPW, ROWSPLIT, PIPE>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<R, TPW, ROWSPLIT>), grid, dim3(512), lds, s,
-                     a);
+  hipLaunchKernelGGL((wgrad_kernel<R, TPW, ROWSPLIT, PIPE>), grid, dim3(512),
+                     lds, s, a);
   CG_LAUNCH_CHECK();
+}
+
+template <int R, int TPW, bool ROWSPLIT>
+int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, bool pipe,
+                 hipStream_t s) {
+  if (pipe) return launch_wgrad1<R, TPW, ROWSPLIT, true>(a, grid, 2 * lds, s);
+  return launch_wgrad1<R, TPW, ROWSPLIT, false>(a, grid, lds, s);
 }
 
 }  // namespace
@@ -231,18 +336,23 @@ extern "C" int cg_wgrad(const cg_wgrad_desc* d, void* stream) {
   const size_t lds =
       ((size_t)R * a.nseg * a.WR * kPitchX + (size_t)TT * kPitchG) * 2;
   if (lds > 160 * 1024) return CG_EINVAL;
+  const bool pipe = a.nseg == 1 && 2 * lds <= 160 * 1024;
   const int gx = (d->Cx_real + 31) / 32;
   const int gy = (d->Cg_real + 63) / 64;
   int nsplit = d->nsplit;
   if (nsplit <= 0) {
-    nsplit = (1024 + gx * gy - 1) / (gx * gy);  // ~4 blocks per CU
+    // one 8-wave workgroup per CU is resident (152 VGPRs); every extra K'
+    // split costs a full dW tile of f32 atomics (chip-wide ~1.3 TB/s), so
+    // split just enough to fill the 256 CUs once
+    nsplit = 256 / (gx * gy);
+    if (nsplit < 1) nsplit = 1;
   }
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   if (nsplit < 1) nsplit = 1;
   dim3 grid(gx, gy, nsplit);
   hipStream_t s = (hipStream_t)stream;
-  if (rowsplit) return launch_wgrad<1, 1, true>(a, grid, lds, s);
-  if (d->taps <= 8) return launch_wgrad<2, 1, false>(a, grid, lds, s);
-  if (d->taps <= 16) return launch_wgrad<2, 2, false>(a, grid, lds, s);
-  return launch_wgrad<2, 3, false>(a, grid, lds, s);
+  if (rowsplit) return launch_wgrad<1, 1, true>(a, grid, lds, pipe, s);
+  if (d->taps <= 8) return launch_wgrad<2, 1, false>(a, grid, lds, pipe, s);
+  if (d->taps <= 16) return launch_wgrad<2, 2, false>(a, grid, lds, pipe, s);
+  return launch_wgrad<2, 3, false>(a, grid, lds, pipe, s);
 }

@@ -9,7 +9,7 @@ from collections import namedtuple
 
 NUM_CONVS = 5
 LDS_BYTES = 160 * 1024
-_LDS_B = 64 * 136 * 2
+_LDS_B = 2 * 64 * 144 * 2  # double-buffered weight stage
 _SCRATCH = 4 * 16 * 68 * 4
 
 
@@ -57,26 +57,12 @@ def tile_rows(Lu, M, n_tiles_n):
 
 def lds_bytes(CK, stride, taps, Lu, TM):
   c8 = CK // 8
-  pitch_a = CK + (16 if c8 & 1 else 8)
+  pitch_a = CK + 8 * ((6 - (c8 & 3)) & 3)  # 16-byte slots == 2 (mod 4)
   S = min(Lu, TM)
   nseg = TM // S
   WR = S + taps // stride - 1
   a = max(stride * nseg * WR * pitch_a * 2, _SCRATCH)
   return round_up(a, 16) + _LDS_B
-
-
-def choose_ck(Cx, stride, taps, Lu, TM):
-  """Channel chunk of the packed operand: a divisor of the pitch, multiple of
-  8, >= 32; prefer the largest <= 64 (two workgroups per CU), fall back to
-  larger chunks when the pitch has no such divisor (e.g. 104)."""
-  cands = [d for d in range(32, Cx + 1, 8) if Cx % d == 0]
-  pref = sorted([d for d in cands if d <= 64], reverse=True) + sorted(
-      [d for d in cands if d > 64])
-  for d in pref:
-    if lds_bytes(d, stride, taps, Lu, TM) <= LDS_BYTES:
-      return d
-  raise ValueError('no channel chunk fits LDS for Cx={} taps={} Lu={}'.format(
-      Cx, taps, Lu))
 
 
 ConvLayer = namedtuple('ConvLayer', 'cin cout lin lout cinp coutp')

@@ -121,11 +121,17 @@ def _transpose_phases(k, pad_left):
   return out
 
 
+CK_TARGET = {1: 64, 2: 32}  # preferred channel chunk per source stride
+
+
 def _ck_for(Cx, stride, taps, Lu):
-  """One CK valid for both row tiles the launcher may pick for this layer."""
+  """Channel chunk of a packed operand: a divisor of the pitch, multiple of 8,
+  >= 32, valid for both row tiles the launcher may pick.  Preference: the chunk
+  that keeps one workgroup's LDS under half the CU (two resident workgroups
+  hide each other's staging): 32 for stride-2 windows, 64 for stride-1."""
   cands = [d for d in range(32, Cx + 1, 8) if Cx % d == 0]
-  pref = sorted([d for d in cands if d <= 64], reverse=True) + sorted(
-      [d for d in cands if d > 64])
+  tgt = CK_TARGET[stride]
+  pref = sorted(cands, key=lambda d: (d > tgt, abs(d - tgt)))
   tms = [tm for tm in (256, 64)
          if ((Lu % tm == 0) if Lu >= tm else (tm % Lu == 0))]
   if not tms:
