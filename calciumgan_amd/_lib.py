@@ -33,6 +33,7 @@ class ConvDesc(C.Structure):
       ('w_phase_stride', c_ll),
       ('off_phase_step', c_i), ('yoff_phase_step', c_i),
       ('small_tile', c_i),
+      ('stage_ksteps', c_i),
   ]
 
 

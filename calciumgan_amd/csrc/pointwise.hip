@@ -32,69 +32,103 @@ __device__ __forceinline__ void store8(uint16_t* p, const float* v) {
 }
 
 // ---------------------------------------------------------------------------
-// LayerNorm + LeakyReLU.  One wave per row; Cp <= 512 -> one 8-channel group
-// per lane.
+// LayerNorm + LeakyReLU.  A row (Cp <= 512 channels) is covered by LPR lanes
+// of 8 channels each (LPR = power of two >= Cp/8), so one wave processes
+// 64/LPR rows at a time; row statistics reduce with xor-shuffles inside the
+// LPR-lane group.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+  for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(
     const uint16_t* __restrict__ y, const float* __restrict__ gamma,
     const float* __restrict__ beta, uint16_t* __restrict__ h,
     float* __restrict__ mean_o, float* __restrict__ rstd_o, long long rows,
-    int C, int Cp, float eps, float alpha) {
+    int C, int Cp, float eps, float alpha, int lpr, int log2lpr,
+    int rows_per_slot) {
   const int lane = threadIdx.x & 63;
-  const long long row =
+  const int sub = lane & (lpr - 1);        // channel group inside the row
+  const int slot = lane >> log2lpr;        // row slot inside the wave
+  const int rpw = 64 >> log2lpr;           // rows per wave per iteration
+  const long long wave_id =
       (long long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int c0 = lane * 8;
-  float v[8];
+  const int c0 = sub * 8;
   const bool active = c0 < Cp;
-  if (active) load8(y + row * Cp + c0, v);
-  float s = 0.f;
+  float gam[8], bet[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e)
-    if (active && c0 + e < C) s += v[e];
-  const float mean = wave_sum(s) / C;
-  float s2 = 0.f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e)
-    if (active && c0 + e < C) {
-      const float d = v[e] - mean;
-      s2 += d * d;
-    }
-  const float rstd = rsqrtf(wave_sum(s2) / C + eps);
-  if (lane == 0) {
-    if (mean_o) mean_o[row] = mean;
-    if (rstd_o) rstd_o[row] = rstd;
+  for (int e = 0; e < 8; ++e) {
+    const bool ok = active && c0 + e < C;
+    gam[e] = ok ? gamma[c0 + e] : 0.f;
+    bet[e] = ok ? beta[c0 + e] : 0.f;
   }
-  if (active) {
-    float o[8];
+  const float invC = 1.f / C;
+  const long long row0 = wave_id * (long long)rpw * rows_per_slot + slot;
+  for (int it = 0; it < rows_per_slot; ++it) {
+    const long long row = row0 + (long long)it * rpw;
+    const bool rv = row < rows;  // uniform inside the LPR group
+    float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t = 0.f;
-      if (c0 + e < C) {
-        t = (v[e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
-        t = t > 0.f ? t : alpha * t;
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (rv && active) load8(y + row * Cp + c0, v);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (c0 + e < C) s += v[e];
+    const float mean = group_sum(s, lpr) * invC;
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (active && c0 + e < C) {
+        const float d = v[e] - mean;
+        s2 += d * d;
       }
-      o[e] = t;
+    const float rstd = rsqrtf(group_sum(s2, lpr) * invC + eps);
+    if (rv && sub == 0) {
+      if (mean_o) mean_o[row] = mean;
+      if (rstd_o) rstd_o[row] = rstd;
     }
-    store8(h + row * Cp + c0, o);
+    if (rv && active) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = 0.f;
+        if (c0 + e < C) {
+          t = (v[e] - mean) * rstd * gam[e] + bet[e];
+          t = t > 0.f ? t : alpha * t;
+        }
+        o[e] = t;
+      }
+      store8(h + row * Cp + c0, o);
+    }
   }
 }
 
 // dy = rstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)), dyh = do * gamma,
-// do = dh * lrelu'(h); dgamma += do * xhat, dbeta += do (per-block partials in
-// LDS, then one atomic per channel per block).
+// do = dh * lrelu'(h); dgamma += do * xhat, dbeta += do (per-lane partials ->
+// LDS atomics -> one global atomic per channel per block).
 __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
     const uint16_t* __restrict__ dh, const uint16_t* __restrict__ h,
     const uint16_t* __restrict__ y, const float* __restrict__ mean_i,
     const float* __restrict__ rstd_i, const float* __restrict__ gamma,
     uint16_t* __restrict__ dy, float* __restrict__ dgamma,
     float* __restrict__ dbeta, long long rows, int C, int Cp, float alpha,
-    int rows_per_wave) {
-  __shared__ float sg[4][512];
-  __shared__ float sb[4][512];
+    int lpr, int log2lpr, int rows_per_slot) {
+  __shared__ float sg[512];
+  __shared__ float sb[512];
+  for (int c = threadIdx.x; c < 512; c += kThreads) {
+    sg[c] = 0.f;
+    sb[c] = 0.f;
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int c0 = lane * 8;
+  const int sub = lane & (lpr - 1);
+  const int slot = lane >> log2lpr;
+  const int rpw = 64 >> log2lpr;
+  const long long wave_id =
+      (long long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const int c0 = sub * 8;
   const bool active = c0 < Cp;
   float gam[8], accg[8], accb[8];
 #pragma unroll
@@ -103,26 +137,31 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
     accg[e] = 0.f;
     accb[e] = 0.f;
   }
-  const long long wave_id = (long long)blockIdx.x * 4 + wave;
-  const long long r0 = wave_id * rows_per_wave;
-  for (int rr = 0; rr < rows_per_wave; ++rr) {
-    const long long row = r0 + rr;
-    if (row >= rows) break;
+  const float invC = 1.f / C;
+  const long long row0 = wave_id * (long long)rpw * rows_per_slot + slot;
+  for (int it = 0; it < rows_per_slot; ++it) {
+    const long long row = row0 + (long long)it * rpw;
+    const bool rv = row < rows;
     float vd[8], vh[8], vy[8];
-    if (active) {
-      load8(dh + row * Cp + c0, vd);
-      load8(h + row * Cp + c0, vh);
-      load8(y + row * Cp + c0, vy);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vd[e] = vh[e] = vy[e] = 0.f;
+    float mean = 0.f, rstd = 0.f;
+    if (rv) {
+      mean = mean_i[row];
+      rstd = rstd_i[row];
+      if (active) {
+        load8(dh + row * Cp + c0, vd);
+        load8(h + row * Cp + c0, vh);
+        load8(y + row * Cp + c0, vy);
+      }
     }
-    const float mean = mean_i[row];
-    const float rstd = rstd_i[row];
     float xh[8], dyh[8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       xh[e] = 0.f;
       dyh[e] = 0.f;
-      if (active && c0 + e < C) {
+      if (rv && active && c0 + e < C) {
         const float d_o = vd[e] * (vh[e] > 0.f ? 1.f : alpha);
         xh[e] = (vy[e] - mean) * rstd;
         dyh[e] = d_o * gam[e];
@@ -132,9 +171,9 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
         s2 += dyh[e] * xh[e];
       }
     }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
-    if (active) {
+    s1 = group_sum(s1, lpr) * invC;
+    s2 = group_sum(s2, lpr) * invC;
+    if (rv && active) {
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -144,15 +183,16 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
   }
   if (active) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      sg[wave][c0 + e] = accg[e];
-      sb[wave][c0 + e] = accb[e];
-    }
+    for (int e = 0; e < 8; ++e)
+      if (c0 + e < C) {
+        atomicAdd(&sg[c0 + e], accg[e]);
+        atomicAdd(&sb[c0 + e], accb[e]);
+      }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += kThreads) {
-    atomicAdd(dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
-    atomicAdd(dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+    atomicAdd(dgamma + c, sg[c]);
+    atomicAdd(dbeta + c, sb[c]);
   }
 }
 
@@ -552,9 +592,15 @@ extern "C" int cg_ln_lrelu_fwd(const void* y_pre, const float* gamma,
                                float* rstd, long long rows, int C, int Cp,
                                float eps, float alpha, void* stream) {
   if (Cp % 8 || Cp > 512 || C > Cp || rows < 1) return CG_EINVAL;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid1d(rows, 4, 1LL << 31)),
+  int lpr = 1, l2 = 0;
+  while (lpr * 8 < Cp) { lpr <<= 1; ++l2; }
+  const int rpw = 64 / lpr;
+  const int rows_per_slot = 8;
+  hipLaunchKernelGGL(ln_fwd_kernel,
+                     dim3(grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31)),
                      dim3(kThreads), 0, S_(stream), U16(y_pre), gamma, beta,
-                     U16W(h), mean, rstd, rows, C, Cp, eps, alpha);
+                     U16W(h), mean, rstd, rows, C, Cp, eps, alpha, lpr, l2,
+                     rows_per_slot);
   CG_LAUNCH_CHECK();
 }
 
@@ -564,12 +610,15 @@ extern "C" int cg_ln_lrelu_bwd(const void* dh, const void* h, const void* y_pre,
                                float* dbeta, long long rows, int C, int Cp,
                                float alpha, void* stream) {
   if (Cp % 8 || Cp > 512 || C > Cp || rows < 1) return CG_EINVAL;
-  const int rows_per_wave = 32;
+  int lpr = 1, l2 = 0;
+  while (lpr * 8 < Cp) { lpr <<= 1; ++l2; }
+  const int rpw = 64 / lpr;
+  const int rows_per_slot = 16;
   hipLaunchKernelGGL(ln_bwd_kernel,
-                     dim3(grid1d(rows, 4 * rows_per_wave, 1LL << 31)),
+                     dim3(grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31)),
                      dim3(kThreads), 0, S_(stream), U16(dh), U16(h), U16(y_pre),
                      mean, rstd, gamma, U16W(dy), dgamma, dbeta, rows, C, Cp,
-                     alpha, rows_per_wave);
+                     alpha, lpr, l2, rows_per_slot);
   CG_LAUNCH_CHECK();
 }
 

@@ -51,15 +51,23 @@ struct ConvArgs {
 // {4-11,16-19,28-31} (+32), the 8 lanes of k-group g land on the even slots
 // and the 8 lanes of k-group g+1 (next 16-B chunk) on the odd slots: no bank
 // conflicts.  (An odd pitch gives 2-way conflicts on every fragment read.)
-constexpr int kPitchB = 144;          // 128 + 16 bf16: 18 slots per row
+constexpr int kPitchB4 = 144;         // 128 + 16 bf16: 18 slots per row (KS = 4)
+constexpr int kPitchB2 = 80;          // 64 + 16 bf16: 10 slots per row (KS = 2)
 constexpr int kScrPitch = 68;         // fp32 epilogue scratch pitch
-constexpr int kLdsBBytes = 2 * 64 * kPitchB * 2;  // double-buffered
+constexpr int ldsB_bytes(int ks) {  // double-buffered weight stage
+  return 2 * 64 * (ks == 4 ? kPitchB4 : kPitchB2) * 2;
+}
 constexpr int kScratchBytes = 4 * 16 * kScrPitch * 4;
 
-template <int R, int MT>
+// R: source stride.  MT: 16-row subtiles per wave (tile = 64*MT rows).  KS:
+// MFMA K-steps per weight stage (4: 64x128 stages; 2: 64x64 stages, half the
+// LDS so stride-2 windows still fit two workgroups per CU).
+template <int R, int MT, int KS>
 __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TM = 64 * MT;
+  constexpr int kPitchB = KS == 4 ? kPitchB4 : kPitchB2;
+  constexpr int FS = 4 * KS;  // 16-byte K groups per stage (16 or 8)
   uint16_t* ldsA = reinterpret_cast<uint16_t*>(smem);
   uint16_t* ldsB = ldsA + a.ldsA_elems;
 
@@ -92,28 +100,39 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int totalA = R * regionRows * a.c8;
-  // B staging: thread -> rows (tid >> 4) + 16*i, i = 0..3, 16-byte group
-  // f = tid & 15 (named registers, not arrays: keeps the prefetch out of scratch)
-  const uint16_t* bsrc = wp + (long long)(n0 + (tid >> 4)) * a.Kpack + (tid & 15) * 8;
-  const long long bstep = 16 * a.Kpack;
-  const int bdst = (tid >> 4) * kPitchB + (tid & 15) * 8;
-  constexpr int kBStepDst = 16 * kPitchB;
+  // B staging: a stage is 64 rows x FS 16-byte groups; thread -> group
+  // f = tid % FS, rows tid / FS + (256 / FS) * i for i < FS / 4 (named
+  // registers, not arrays: keeps the prefetch out of scratch)
+  constexpr int NBL = FS / 4;           // loads per thread per stage (4 or 2)
+  constexpr int RSTEP = 256 / FS;       // row step between a thread's loads
+  const int brow = tid / FS;
+  const int bf = tid % FS;
+  const uint16_t* bsrc = wp + (long long)(n0 + brow) * a.Kpack + bf * 8;
+  const long long bstep = (long long)RSTEP * a.Kpack;
+  const int bdst = brow * kPitchB + bf * 8;
+  constexpr int kBStepDst = RSTEP * kPitchB;
   constexpr int kBufB = 64 * kPitchB;  // elements per B buffer
   uint4 b0, b1, b2, b3;
+  b2 = b3 = make_uint4(0u, 0u, 0u, 0u);
 #define CG_LOAD_B(koff)                                                     \
   do {                                                                      \
     b0 = *reinterpret_cast<const uint4*>(bsrc + (koff));                    \
     b1 = *reinterpret_cast<const uint4*>(bsrc + (koff) + bstep);            \
-    b2 = *reinterpret_cast<const uint4*>(bsrc + (koff) + 2 * bstep);        \
-    b3 = *reinterpret_cast<const uint4*>(bsrc + (koff) + 3 * bstep);        \
+    if (NBL == 4) {                                                         \
+      b2 = *reinterpret_cast<const uint4*>(bsrc + (koff) + 2 * bstep);      \
+      b3 = *reinterpret_cast<const uint4*>(bsrc + (koff) + 3 * bstep);      \
+    }                                                                       \
   } while (0)
 #define CG_STORE_B(buf)                                                     \
   do {                                                                      \
     *reinterpret_cast<uint4*>((buf) + bdst) = b0;                           \
     *reinterpret_cast<uint4*>((buf) + bdst + kBStepDst) = b1;               \
-    *reinterpret_cast<uint4*>((buf) + bdst + 2 * kBStepDst) = b2;           \
-    *reinterpret_cast<uint4*>((buf) + bdst + 3 * kBStepDst) = b3;           \
+    if (NBL == 4) {                                                         \
+      *reinterpret_cast<uint4*>((buf) + bdst + 2 * kBStepDst) = b2;         \
+      *reinterpret_cast<uint4*>((buf) + bdst + 3 * kBStepDst) = b3;         \
+    }                                                                       \
   } while (0)
+  const int nstages = a.Fp / FS;
 
   for (int cc = 0; cc < a.nchunks; ++cc) {
     // first B stage of this chunk: issue the loads before touching LDS so
@@ -175,13 +194,13 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
 
     // per-lane flattened K position inside the chunk: f = 4*kstep + g
     int tap = 0, q8l = g;  // c8 >= 4
-    for (int s = 0; s < a.nstages; ++s) {
+    for (int s = 0; s < nstages; ++s) {
       const uint16_t* curB = ldsB + (s & 1) * kBufB;
-      const bool more = s + 1 < a.nstages;
-      if (more)  // prefetch the next 64 x 128 weight stage into registers
-        CG_LOAD_B(((long long)cc * a.Fp + 16 * (s + 1)) * 8);
+      const bool more = s + 1 < nstages;
+      if (more)  // prefetch the next weight stage into registers
+        CG_LOAD_B(((long long)cc * a.Fp + FS * (s + 1)) * 8);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         const int t = tap < a.taps ? tap : a.taps - 1;  // padded K: B is zero
         int aoff;
         if (R == 2)
@@ -228,7 +247,11 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         scr[(4 * g + r) * kScrPitch + nt * 16 + r16] = acc[mt][nt][r];
-    __syncthreads();
+    // the scratch is private to this wave and a wave's LDS ops complete in
+    // order: a wave barrier (no s_barrier) is enough
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int i = wave * 16 * MT + mt * 16 + erow;
     const int m = m0 + i;
     if (m < a.M) {
@@ -282,7 +305,9 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
         }
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -355,18 +380,19 @@ extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {
   CG_LAUNCH_CHECK();
 }
 
-template <int R, int MT>
+template <int R, int MT, int KS>
 static int launch_swconv(const ConvArgs& a, dim3 grid, size_t lds,
                          hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&swconv_kernel<R, MT>),
+        reinterpret_cast<const void*>(&swconv_kernel<R, MT, KS>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((swconv_kernel<R, MT>), grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((swconv_kernel<R, MT, KS>), grid, dim3(256), lds, stream,
+                     a);
   CG_LAUNCH_CHECK();
 }
 
@@ -405,7 +431,7 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   a.CK = d->CK; a.c8 = d->CK / 8; a.nchunks = d->Cx / d->CK;
   a.inv_c8 = 1.0f / (float)a.c8;
   a.Fp = (d->taps * a.c8 + 15) / 16 * 16;
-  a.nstages = a.Fp / 16;
+  a.nstages = a.Fp / 16;  // 128-wide stages; the kernel derives its own
   a.Kpack = (long long)a.nchunks * a.Fp * 8;
   a.pitchA = d->CK + 8 * ((6 - (a.c8 & 3)) & 3);  // slots == 2 (mod 4)
   a.S = S; a.log2S = ilog2(S); a.nseg = TM / S;
@@ -419,12 +445,25 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   if (ldsA_bytes < (size_t)kScratchBytes) ldsA_bytes = kScratchBytes;
   ldsA_bytes = (ldsA_bytes + 15) / 16 * 16;
   a.ldsA_elems = (int)(ldsA_bytes / 2);
-  const size_t lds = ldsA_bytes + kLdsBBytes;
+  // weight-stage width: 128 K-elements when two workgroups still fit a CU with
+  // it (or when nothing would), else 64
+  const size_t half_cu = 80 * 1024;
+  int ks = 4;
+  if (ldsA_bytes + ldsB_bytes(4) > half_cu && ldsA_bytes + ldsB_bytes(2) <= half_cu)
+    ks = 2;
+  if (d->stage_ksteps == 2 || d->stage_ksteps == 4) ks = d->stage_ksteps;
+  const size_t lds = ldsA_bytes + ldsB_bytes(ks);
   if (lds > 160 * 1024) return CG_EINVAL;
   dim3 grid((a.M + TM - 1) / TM, (d->N + 63) / 64, d->nphase);
   hipStream_t s = (hipStream_t)stream;
-  if (R == 1 && !d->small_tile) return launch_swconv<1, 4>(a, grid, lds, s);
-  if (R == 1 && d->small_tile) return launch_swconv<1, 1>(a, grid, lds, s);
-  if (R == 2 && !d->small_tile) return launch_swconv<2, 4>(a, grid, lds, s);
-  return launch_swconv<2, 1>(a, grid, lds, s);
+  if (ks == 4) {
+    if (R == 1 && !d->small_tile) return launch_swconv<1, 4, 4>(a, grid, lds, s);
+    if (R == 1 && d->small_tile) return launch_swconv<1, 1, 4>(a, grid, lds, s);
+    if (R == 2 && !d->small_tile) return launch_swconv<2, 4, 4>(a, grid, lds, s);
+    return launch_swconv<2, 1, 4>(a, grid, lds, s);
+  }
+  if (R == 1 && !d->small_tile) return launch_swconv<1, 4, 2>(a, grid, lds, s);
+  if (R == 1 && d->small_tile) return launch_swconv<1, 1, 2>(a, grid, lds, s);
+  if (R == 2 && !d->small_tile) return launch_swconv<2, 4, 2>(a, grid, lds, s);
+  return launch_swconv<2, 1, 2>(a, grid, lds, s);
 }

@@ -9,7 +9,7 @@ from collections import namedtuple
 
 NUM_CONVS = 5
 LDS_BYTES = 160 * 1024
-_LDS_B = 2 * 64 * 144 * 2  # double-buffered weight stage
+_LDS_B = 2 * 64 * 80 * 2  # smallest (64-wide) double-buffered weight stage
 _SCRATCH = 4 * 16 * 68 * 4
 
 

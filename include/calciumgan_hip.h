@@ -77,6 +77,7 @@ typedef struct cg_conv_desc {
   long long w_phase_stride; /* elements */
   int off_phase_step, yoff_phase_step;
   int small_tile;       /* 0: 256-row tiles, 1: 64-row tiles */
+  int stage_ksteps;     /* 0: choose; 2 or 4: MFMA K-steps per weight stage */
 } cg_conv_desc;
 
 int cg_swconv(const cg_conv_desc* d, void* stream);
