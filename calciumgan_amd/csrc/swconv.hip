@@ -22,6 +22,8 @@
 //     v_mfma_f32_16x16x32_bf16, fp32 accumulate; epilogue goes through LDS so
 //     global stores are 16-byte and row-contiguous, with bias / LeakyReLU /
 //     LeakyReLU-derivative mask / sigmoid fused.
+#include <type_traits>
+
 #include "cg_common.h"
 
 namespace {
@@ -42,6 +44,7 @@ struct ConvArgs {
   int epilogue, out_f32;
   float alpha;
   float inv_c8;
+  int log2c8;  // log2(c8) when c8 is a power of two, else -1
   long long w_phase_stride;
   int off_phase_step, yoff_phase_step;
 };
@@ -59,10 +62,11 @@ constexpr int ldsB_bytes(int ks) {  // double-buffered weight stage
 }
 constexpr int kScratchBytes = 4 * 16 * kScrPitch * 4;
 
+// UNI: 4 | c8, the K walk is wave-uniform (see the chunk loop).
 // R: source stride.  MT: 16-row subtiles per wave (tile = 64*MT rows).  KS:
 // MFMA K-steps per weight stage (4: 64x128 stages; 2: 64x64 stages, half the
 // LDS so stride-2 windows still fit two workgroups per CU).
-template <int R, int MT, int KS>
+template <int R, int MT, int KS, bool UNI>
 __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TM = 64 * MT;
@@ -150,19 +154,40 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
       const int sft = (a.shifts && valid) ? a.shifts[b / a.seg_size] : 0;
       const uint16_t* xb = a.x + (long long)b * a.Lx * a.Cx + cc * a.CK;
       const int srow0 = R * u0 + off;
-      for (int idx = tid; idx < totalA; idx += 256) {
-        const int row = __float2int_rz(((float)idx + 0.5f) * a.inv_c8);
-        const int q8 = idx - row * a.c8;
-        const int rho = (R == 2 && row >= a.WR) ? 1 : 0;
-        const int wr = row - rho * a.WR;
-        int srow = srow0 + R * wr + rho;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (valid && srow >= 0 && srow < a.Lx) {
-          if (a.shifts) srow = shuffle_src(srow, sft, a.Lx);
-          v = *reinterpret_cast<const uint4*>(xb + (long long)srow * a.Cx +
-                                              q8 * 8);
+      if (a.log2c8 >= 0) {
+        // c8 is a power of two: a thread keeps its 16-byte column and walks
+        // rows with a constant step -> no per-piece index arithmetic
+        const int q8 = tid & (a.c8 - 1);
+        const int rstep = 256 >> a.log2c8;
+        const uint16_t* xq = xb + q8 * 8;
+        uint16_t* dst = ldsA + (tid >> a.log2c8) * a.pitchA + q8 * 8;
+        const int dstep = rstep * a.pitchA;
+        for (int row = tid >> a.log2c8; row < R * a.WR; row += rstep) {
+          const int rho = (R == 2 && row >= a.WR) ? 1 : 0;
+          int srow = srow0 + R * (row - rho * a.WR) + rho;
+          uint4 v = make_uint4(0u, 0u, 0u, 0u);
+          if (valid && srow >= 0 && srow < a.Lx) {
+            if (a.shifts) srow = shuffle_src(srow, sft, a.Lx);
+            v = *reinterpret_cast<const uint4*>(xq + (long long)srow * a.Cx);
+          }
+          *reinterpret_cast<uint4*>(dst) = v;
+          dst += dstep;
         }
-        *reinterpret_cast<uint4*>(ldsA + row * a.pitchA + q8 * 8) = v;
+      } else {
+        for (int idx = tid; idx < totalA; idx += 256) {
+          const int row = __float2int_rz(((float)idx + 0.5f) * a.inv_c8);
+          const int q8 = idx - row * a.c8;
+          const int rho = (R == 2 && row >= a.WR) ? 1 : 0;
+          const int wr = row - rho * a.WR;
+          int srow = srow0 + R * wr + rho;
+          uint4 v = make_uint4(0u, 0u, 0u, 0u);
+          if (valid && srow >= 0 && srow < a.Lx) {
+            if (a.shifts) srow = shuffle_src(srow, sft, a.Lx);
+            v = *reinterpret_cast<const uint4*>(xb + (long long)srow * a.Cx +
+                                                q8 * 8);
+          }
+          *reinterpret_cast<uint4*>(ldsA + row * a.pitchA + q8 * 8) = v;
+        }
       }
     } else {
       for (int idx = tid; idx < totalA; idx += 256) {
@@ -192,45 +217,52 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
     CG_STORE_B(ldsB);
     __syncthreads();
 
-    // per-lane flattened K position inside the chunk: f = 4*kstep + g
-    int tap = 0, q8l = g;  // c8 >= 4
-    for (int s = 0; s < nstages; ++s) {
-      const uint16_t* curB = ldsB + (s & 1) * kBufB;
-      const bool more = s + 1 < nstages;
-      if (more)  // prefetch the next weight stage into registers
-        CG_LOAD_B(((long long)cc * a.Fp + FS * (s + 1)) * 8);
+    // Flattened K position inside the chunk: 16-byte group f = 4*kstep + g.
+    // When 4 | c8 the four k-groups of a K-step share one tap and the walk is
+    // wave-uniform (scalar registers, lane part g*8 folded into the row base);
+    // otherwise (e.g. c8 = 13) every lane tracks its own (tap, group).
+    {
+      int tap = 0;
+      int q8l = UNI ? 0 : g;  // c8 >= 4
+      const int goff = UNI ? g * 8 : 0;
+      for (int s = 0; s < nstages; ++s) {
+        const uint16_t* curB = ldsB + (s & 1) * kBufB;
+        const bool more = s + 1 < nstages;
+        if (more)  // prefetch the next weight stage into registers
+          CG_LOAD_B(((long long)cc * a.Fp + FS * (s + 1)) * 8);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int t = tap < a.taps ? tap : a.taps - 1;  // padded K: B is zero
-        int aoff;
-        if (R == 2)
-          aoff = ((t & 1) * regionRows + (t >> 1)) * a.pitchA + q8l * 8;
-        else
-          aoff = t * a.pitchA + q8l * 8;
-        bf16x8 bfrag[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          bfrag[nt] = *reinterpret_cast<const bf16x8*>(
-              curB + (nt * 16 + r16) * kPitchB + (4 * ks + g) * 8);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const bf16x8 afrag =
-              *reinterpret_cast<const bf16x8*>(ldsA + rowbase[mt] + aoff);
+        for (int ks = 0; ks < KS; ++ks) {
+          const int t = tap < a.taps ? tap : a.taps - 1;  // padded K: B is zero
+          int aoff;
+          if (R == 2)
+            aoff = ((t & 1) * regionRows + (t >> 1)) * a.pitchA + q8l * 8;
+          else
+            aoff = t * a.pitchA + q8l * 8;
+          bf16x8 bfrag[4];
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                afrag, bfrag[nt], acc[mt][nt], 0, 0, 0);
+            bfrag[nt] = *reinterpret_cast<const bf16x8*>(
+                curB + (nt * 16 + r16) * kPitchB + (4 * ks + g) * 8);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(
+                ldsA + (rowbase[mt] + goff) + aoff);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  afrag, bfrag[nt], acc[mt][nt], 0, 0, 0);
+          }
+          q8l += 4;
+          if (q8l >= a.c8) {
+            q8l -= a.c8;
+            ++tap;
+          }
         }
-        q8l += 4;
-        if (q8l >= a.c8) {
-          q8l -= a.c8;
-          ++tap;
+        if (more) {
+          uint16_t* nxtB = ldsB + ((s + 1) & 1) * kBufB;
+          CG_STORE_B(nxtB);
+          __syncthreads();
         }
-      }
-      if (more) {
-        uint16_t* nxtB = ldsB + ((s + 1) & 1) * kBufB;
-        CG_STORE_B(nxtB);
-        __syncthreads();
       }
     }
   }
@@ -240,6 +272,14 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
   float* scr = reinterpret_cast<float*>(smem) + wave * (16 * kScrPitch);
   const int erow = lane >> 2;
   const int ecol = (lane & 3) * 16;
+  float bv[2][8];  // this lane's 16 output channels' bias (0 when absent/pad)
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = n0 + ecol + 8 * half + e;
+      bv[half][e] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+    }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -270,27 +310,28 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
               scr + erow * kScrPitch + ecol + 8 * half + 4);
           v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
           v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
-          uint4 hm = make_uint4(0u, 0u, 0u, 0u);
-          if (a.epilogue == CG_EPI_MASK)
-            hm = *reinterpret_cast<const uint4*>(a.mask + rowoff + n);
-          const uint32_t hw[4] = {hm.x, hm.y, hm.z, hm.w};
+          const int nval = a.N - n;  // valid channels in this 8-group
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float t = v[e];
-            if (n + e < a.N) {
-              if (a.bias) t += a.bias[n + e];
-              if (a.epilogue == CG_EPI_LRELU) {
-                t = t > 0.f ? t : a.alpha * t;
-              } else if (a.epilogue == CG_EPI_MASK) {
-                const uint16_t hb = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
-                t *= (bf2f(hb) > 0.f) ? 1.f : a.alpha;
-              } else if (a.epilogue == CG_EPI_SIGMOID) {
-                t = 1.f / (1.f + __expf(-t));
-              }
-            } else {
-              t = 0.f;
+          for (int e = 0; e < 8; ++e) v[e] += bv[half][e];
+          if (a.epilogue == CG_EPI_LRELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], a.alpha * v[e]);
+          } else if (a.epilogue == CG_EPI_MASK) {
+            const uint4 hm = *reinterpret_cast<const uint4*>(a.mask + rowoff + n);
+            const uint32_t hw[4] = {hm.x, hm.y, hm.z, hm.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const uint16_t hb = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
+              v[e] *= (bf2f(hb) > 0.f) ? 1.f : a.alpha;
             }
-            v[e] = t;
+          } else if (a.epilogue == CG_EPI_SIGMOID) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+          }
+          if (nval < 8) {  // channel padding stays exactly zero
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (e >= nval) v[e] = 0.f;
           }
           if (a.out_f32) {
             float* dst = reinterpret_cast<float*>(a.y) + rowoff + n;
@@ -380,20 +421,27 @@ extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {
   CG_LAUNCH_CHECK();
 }
 
-template <int R, int MT, int KS>
-static int launch_swconv(const ConvArgs& a, dim3 grid, size_t lds,
-                         hipStream_t stream) {
+template <int R, int MT, int KS, bool UNI>
+static int launch_swconv1(const ConvArgs& a, dim3 grid, size_t lds,
+                          hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&swconv_kernel<R, MT, KS>),
+        reinterpret_cast<const void*>(&swconv_kernel<R, MT, KS, UNI>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((swconv_kernel<R, MT, KS>), grid, dim3(256), lds, stream,
-                     a);
+  hipLaunchKernelGGL((swconv_kernel<R, MT, KS, UNI>), grid, dim3(256), lds,
+                     stream, a);
   CG_LAUNCH_CHECK();
+}
+
+template <int R, int MT, int KS>
+static int launch_swconv(const ConvArgs& a, dim3 grid, size_t lds,
+                         hipStream_t stream) {
+  if ((a.c8 & 3) == 0) return launch_swconv1<R, MT, KS, true>(a, grid, lds, stream);
+  return launch_swconv1<R, MT, KS, false>(a, grid, lds, stream);
 }
 
 extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
@@ -407,7 +455,7 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   if (d->epilogue == CG_EPI_MASK && !d->mask_src) return CG_EINVAL;
   if (d->shifts && d->seg_size < 1) return CG_EINVAL;
   const int R = d->stride;
-  const int TM = d->small_tile ? 64 : 256;
+  const int TM = d->small_tile == 1 ? 64 : (d->small_tile == 2 ? 128 : 256);
   int S;
   if (d->Lu >= TM) {
     if (d->Lu % TM) return CG_EINVAL;
@@ -430,6 +478,7 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   a.y_off = d->y_off;
   a.CK = d->CK; a.c8 = d->CK / 8; a.nchunks = d->Cx / d->CK;
   a.inv_c8 = 1.0f / (float)a.c8;
+  a.log2c8 = (a.c8 & (a.c8 - 1)) ? -1 : ilog2(a.c8);
   a.Fp = (d->taps * a.c8 + 15) / 16 * 16;
   a.nstages = a.Fp / 16;  // 128-wide stages; the kernel derives its own
   a.Kpack = (long long)a.nchunks * a.Fp * 8;
@@ -456,14 +505,13 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   if (lds > 160 * 1024) return CG_EINVAL;
   dim3 grid((a.M + TM - 1) / TM, (d->N + 63) / 64, d->nphase);
   hipStream_t s = (hipStream_t)stream;
-  if (ks == 4) {
-    if (R == 1 && !d->small_tile) return launch_swconv<1, 4, 4>(a, grid, lds, s);
-    if (R == 1 && d->small_tile) return launch_swconv<1, 1, 4>(a, grid, lds, s);
-    if (R == 2 && !d->small_tile) return launch_swconv<2, 4, 4>(a, grid, lds, s);
-    return launch_swconv<2, 1, 4>(a, grid, lds, s);
-  }
-  if (R == 1 && !d->small_tile) return launch_swconv<1, 4, 2>(a, grid, lds, s);
-  if (R == 1 && d->small_tile) return launch_swconv<1, 1, 2>(a, grid, lds, s);
-  if (R == 2 && !d->small_tile) return launch_swconv<2, 4, 2>(a, grid, lds, s);
-  return launch_swconv<2, 1, 2>(a, grid, lds, s);
+  const int mt = TM / 64;
+#define CG_DISPATCH(RR, MM, KK) \
+  if (R == RR && mt == MM && ks == KK) return launch_swconv<RR, MM, KK>(a, grid, lds, s);
+  CG_DISPATCH(1, 4, 4) CG_DISPATCH(1, 2, 4) CG_DISPATCH(1, 1, 4)
+  CG_DISPATCH(2, 4, 4) CG_DISPATCH(2, 2, 4) CG_DISPATCH(2, 1, 4)
+  CG_DISPATCH(1, 4, 2) CG_DISPATCH(1, 2, 2) CG_DISPATCH(1, 1, 2)
+  CG_DISPATCH(2, 4, 2) CG_DISPATCH(2, 2, 2) CG_DISPATCH(2, 1, 2)
+#undef CG_DISPATCH
+  return CG_EINVAL;
 }

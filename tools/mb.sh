@@ -1,17 +1,9 @@
 B=tools/bench_conv.py
-python $B conv 1 1 128 2048 104 102 104 0 3 1
-python $B conv 1 1 128 2048 104 102 104 1 3 1
-python $B conv 2 24 384 512 128 192 32 0 1 0 0
-python $B conv 2 24 384 512 128 192 32 0 1 0 4
-python $B conv 2 24 384 512 128 192 64 0 1 0 0
-python $B conv 2 24 384 2048 104 64 104 0 1 0 0
-python $B conv 2 24 384 256 192 256 32 0 1 0 0
-python $B conv 2 24 384 256 192 256 32 0 1 0 4
-python $B conv 2 24 384 128 256 320 32 0 1 0 0
-python $B conv 2 24 384 1024 64 128 32 0 1 0 0
-python $B conv 2 24 384 1024 64 128 64 0 1 0 0
-python $B conv 1 12 384 256 192 128 64 0 0 0 0
-python $B conv 1 12 384 256 192 128 64 0 0 0 2
-python $B conv 1 12 384 64 320 256 64 0 0 0 0
-python $B conv 1 12 384 64 320 256 64 1 0 0 0
-python $B conv 1 12 128 1024 128 102 64 0 0 0 0
+for small in 0 2; do for ks in 0 2 4; do
+python $B conv 2 24 384 512 128 192 32 $small 1 0 $ks
+python $B conv 2 24 384 512 128 192 64 $small 1 0 $ks
+done; done
+for small in 0 2; do for ks in 2 4; do
+python $B conv 1 12 384 256 192 128 64 $small 0 0 $ks
+python $B conv 2 24 384 2048 104 64 104 $small 1 0 $ks
+done; done
