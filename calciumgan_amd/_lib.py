@@ -65,6 +65,9 @@ SIGNATURES = {
     'cg_swconv': [C.POINTER(ConvDesc), c_vp],
     'cg_packed_elems': [c_i, c_i, c_i, c_i],
     'cg_pack_weights': [C.POINTER(PackDesc), c_vp],
+    'cg_pack_plan_bytes': [c_i, c_ll],
+    'cg_pack_plan_build': [C.POINTER(PackDesc), c_i, c_vp, c_ll],
+    'cg_pack_batched': [c_vp, c_i, c_ll, c_vp],
     'cg_wgrad': [C.POINTER(WgradDesc), c_vp],
     'cg_ln_lrelu_fwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_f,
                         c_f, c_vp],
@@ -78,7 +81,7 @@ SIGNATURES = {
     'cg_unshuffle_mask': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f,
                           c_vp],
     'cg_interp_pack': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i,
-                       c_vp],
+                       c_i, c_vp],
     'cg_cast_pad': [c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],
     'cg_rownorm': [c_vp, c_vp, c_i, c_ll, c_vp],
     'cg_gp_finalize': [c_vp, c_vp, c_vp, c_i, c_f, c_vp],
@@ -88,11 +91,13 @@ SIGNATURES = {
     'cg_colsum': [c_vp, c_vp, c_ll, c_i, c_i, c_vp],
     'cg_sigmoid_bwd': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],
     'cg_lrelu_bwd': [c_vp, c_vp, c_vp, c_ll, c_f, c_vp],
-    'cg_adam': [c_vp, c_vp, c_vp, c_vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_vp],
+    'cg_adam': [c_vp, c_vp, c_vp, c_vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_vp,
+                c_vp],
     'cg_signal_metrics': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_f, c_f,
                           c_vp],
 }
-_RESTYPES = {'cg_packed_elems': c_ll}
+_RESTYPES = {'cg_packed_elems': c_ll, 'cg_pack_plan_bytes': c_ll,
+             'cg_pack_plan_build': c_ll}
 
 _lib = None
 

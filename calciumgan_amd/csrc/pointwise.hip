@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kThreads) void unshuffle_mask_kernel(
 __global__ __launch_bounds__(kThreads) void interp_pack_kernel(
     const float* __restrict__ real, const float* __restrict__ fake,
     const float* __restrict__ alpha, uint16_t* __restrict__ x0, int B, int L,
-    int C, int Cr, int Cf, int Cp, long long total8) {
+    int C, int Cr, int Cf, int Cp, long long total8, int write_real) {
   const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (idx >= total8) return;
   const int per_row = Cp / 8;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kThreads) void interp_pack_kernel(
     x[e] = al * r[e] + (1.f - al) * f[e];
   }
   const long long seg = (long long)B * L * Cp;
-  store8(x0 + row * Cp + c, r);
+  if (write_real) store8(x0 + row * Cp + c, r);
   store8(x0 + seg + row * Cp + c, f);
   store8(x0 + 2 * seg + row * Cp + c, x);
 }
@@ -519,9 +519,10 @@ __global__ __launch_bounds__(kThreads) void lrelu_bwd_kernel(
 __global__ __launch_bounds__(kThreads) void adam_kernel(
     float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
     float* __restrict__ v, long long n, float lr_t, float b1, float b2,
-    float eps, float gscale) {
+    float eps, float gscale, const float* __restrict__ lr_t_dev) {
   const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
+  if (lr_t_dev) lr_t = lr_t_dev[0];
   const float g = grad[i] * gscale;
   const float mi = b1 * m[i] + (1.f - b1) * g;
   const float vi = b2 * v[i] + (1.f - b2) * g * g;
@@ -674,13 +675,14 @@ extern "C" int cg_unshuffle_mask(const void* e, const void* h, void* delta,
 
 extern "C" int cg_interp_pack(const float* real, const float* fake,
                               const float* alpha, void* x0, int B, int L, int C,
-                              int Cr, int Cf, int Cp, void* stream) {
+                              int Cr, int Cf, int Cp, int write_real,
+                              void* stream) {
   if (Cp % 8 || C > Cp || C > Cr || C > Cf) return CG_EINVAL;
   const long long total8 = (long long)B * L * Cp / 8;
   hipLaunchKernelGGL(interp_pack_kernel,
                      dim3(grid1d(total8, kThreads, 1LL << 31)), dim3(kThreads),
                      0, S_(stream), real, fake, alpha, U16W(x0), B, L, C, Cr,
-                     Cf, Cp, total8);
+                     Cf, Cp, total8, write_real);
   CG_LAUNCH_CHECK();
 }
 
@@ -741,7 +743,11 @@ extern "C" int cg_neg_mean(const float* d_out, float* out, int B, void* stream) 
 extern "C" int cg_colsum(const void* x, float* out, long long rows, int C,
                          int Cp, void* stream) {
   if (Cp % 8 || Cp / 8 > kThreads || C > Cp) return CG_EINVAL;
-  const int rows_per_block = 256;
+  // enough rows per block to amortise the LDS/global atomics, still >= ~512
+  // blocks on the large activations
+  int rows_per_block = 256;
+  while (rows_per_block < 4096 && rows / (rows_per_block * 2) >= 512)
+    rows_per_block *= 2;
   hipLaunchKernelGGL(colsum_kernel,
                      dim3(grid1d(rows, rows_per_block, 1LL << 31)),
                      dim3(kThreads), Cp * sizeof(float), S_(stream), U16(x), out,
@@ -772,11 +778,12 @@ extern "C" int cg_lrelu_bwd(const void* dh, const void* h, void* dpre,
 
 extern "C" int cg_adam(float* p, const float* grad, float* m, float* v,
                        long long n, float lr_t, float beta1, float beta2,
-                       float eps, float grad_scale, void* stream) {
+                       float eps, float grad_scale, const float* lr_t_dev,
+                       void* stream) {
   if (n < 1) return CG_EINVAL;
   hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, kThreads, 1LL << 31)),
                      dim3(kThreads), 0, S_(stream), p, grad, m, v, n, lr_t,
-                     beta1, beta2, eps, grad_scale);
+                     beta1, beta2, eps, grad_scale, lr_t_dev);
   CG_LAUNCH_CHECK();
 }
 

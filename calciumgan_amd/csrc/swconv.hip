@@ -383,6 +383,33 @@ __global__ void pack_kernel(PackArgs a) {
   a.dst[idx] = f2bf(v);
 }
 
+// All operands of one model in ONE launch: `table` holds n PackArgs, block b
+// works on descriptor desc_of_block[b] starting at element
+// (b - first_block[desc]) * 256.
+__global__ void pack_batched_kernel(const PackArgs* __restrict__ table,
+                                    const int* __restrict__ desc_of_block,
+                                    const int* __restrict__ first_block) {
+  const int di = desc_of_block[blockIdx.x];
+  const PackArgs a = table[di];
+  const long long idx =
+      (long long)(blockIdx.x - first_block[di]) * blockDim.x + threadIdx.x;
+  if (idx >= a.total) return;
+  const int e = idx & 7;
+  long long r = idx >> 3;
+  const int f = (int)(r % a.Fp);
+  r /= a.Fp;
+  const int cc = (int)(r % a.nchunks);
+  const int n = (int)(r / a.nchunks);
+  const int tap = f / a.c8;
+  const int q8 = f - tap * a.c8;
+  const int c = cc * a.CK + q8 * 8 + e;
+  float v = 0.f;
+  if (tap < a.taps && c < a.C_real && n < a.N_real)
+    v = a.src[(long long)(a.tap0 + tap * a.tap_step) * a.s_tap + c * a.s_c +
+              n * a.s_n];
+  a.dst[idx] = f2bf(v);
+}
+
 inline int ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
@@ -399,6 +426,61 @@ extern "C" long long cg_packed_elems(int N, int taps, int Cx, int CK) {
   const int Fp = (taps * c8 + 15) / 16 * 16;
   const long long Npad = (N + 63) / 64 * 64;
   return Npad * (long long)(Cx / CK) * Fp * 8;
+}
+
+static int fill_pack_args(const cg_pack_desc* d, PackArgs& a) {
+  const long long total = cg_packed_elems(d->N_real, d->taps, d->Cx, d->CK);
+  if (total < 0 || d->C_real > d->Cx) return CG_EINVAL;
+  a.src = d->src;
+  a.dst = reinterpret_cast<uint16_t*>(d->dst);
+  a.taps = d->taps; a.tap0 = d->tap0; a.tap_step = d->tap_step;
+  a.s_tap = d->s_tap; a.s_c = d->s_c; a.s_n = d->s_n;
+  a.C_real = d->C_real; a.N_real = d->N_real; a.CK = d->CK;
+  a.c8 = d->CK / 8; a.nchunks = d->Cx / d->CK;
+  a.Fp = (d->taps * a.c8 + 15) / 16 * 16;
+  a.Kpack = (long long)a.nchunks * a.Fp * 8;
+  a.total = total;
+  return 0;
+}
+
+extern "C" long long cg_pack_plan_bytes(int n, long long total_blocks) {
+  return (long long)n * sizeof(PackArgs) + (total_blocks + n) * sizeof(int);
+}
+
+extern "C" long long cg_pack_plan_build(const cg_pack_desc* descs, int n,
+                                        void* host_buf, long long host_bytes) {
+  // pass 1: block counts
+  long long blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    PackArgs a;
+    if (fill_pack_args(descs + i, a)) return -1;
+    blocks += (a.total + 255) / 256;
+  }
+  if (!host_buf) return blocks;
+  if (host_bytes < cg_pack_plan_bytes(n, blocks)) return -1;
+  PackArgs* table = reinterpret_cast<PackArgs*>(host_buf);
+  int* desc_of_block = reinterpret_cast<int*>(table + n);
+  int* first_block = desc_of_block + blocks;
+  long long b = 0;
+  for (int i = 0; i < n; ++i) {
+    fill_pack_args(descs + i, table[i]);
+    first_block[i] = (int)b;
+    const long long nb = (table[i].total + 255) / 256;
+    for (long long k = 0; k < nb; ++k) desc_of_block[b + k] = i;
+    b += nb;
+  }
+  return blocks;
+}
+
+extern "C" int cg_pack_batched(const void* dev_plan, int n, long long blocks,
+                               void* stream) {
+  if (!dev_plan || n < 1 || blocks < 1) return CG_EINVAL;
+  const PackArgs* table = reinterpret_cast<const PackArgs*>(dev_plan);
+  const int* desc_of_block = reinterpret_cast<const int*>(table + n);
+  const int* first_block = desc_of_block + blocks;
+  hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, table, desc_of_block, first_block);
+  CG_LAUNCH_CHECK();
 }
 
 extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {

@@ -28,10 +28,13 @@ class Optimizer(object):
   def get_unscaled_gradients(self, scaled_gradients):
     return scaled_gradients
 
-  def update(self, model, grad_scale=1.0):
+  def lr_t(self, step):
+    return nets.adam_lr_t(step, self.learning_rate)
+
+  def update(self, model, grad_scale=1.0, lr_t_dev=None):
     """Apply the gradients already accumulated in model.net.params.grad
     (optimizer.py:31-34) and refresh the packed bf16 operands."""
     self._iterations += 1
     nets.adam_update(model.net.params, self._iterations, self.learning_rate,
-                     grad_scale)
+                     grad_scale, lr_t_dev=lr_t_dev)
     model.net.repack()

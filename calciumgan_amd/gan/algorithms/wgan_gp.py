@@ -20,12 +20,19 @@ the discriminator as ONE batch of 3B samples (per-segment phase shifts):
 Generator step (reference :22-36): G forward (activations kept), D forward and
 input-gradient chain on fake, generator backward, Adam, signal metrics.
 """
+import os
+
 import torch
 
 from ... import _lib
 from ... import nets
 from .gan import GAN
 from .registry import register
+
+# Whole-step hipGraph capture (single-process runs): the ~370 launches of one
+# train() replay as one graph, removing launch gaps.  CALCIUMGAN_GRAPH=0
+# disables it; it is never used under data parallelism (RCCL calls stay eager).
+_GRAPH_WARMUP_CALLS = 2
 
 
 @register('wgan-gp')
@@ -39,6 +46,8 @@ class WGAN_GP(GAN):
     if self.conv2d:
       raise ValueError('calciumgan_amd: conv2d models are out of scope')
     self._state = {}
+    self._use_graph = (os.environ.get('CALCIUMGAN_GRAPH', '1') != '0' and
+                       self._sync.world == 1)
 
   # -- per-batch-size state ---------------------------------------------------
   def _get_state(self, B):
@@ -70,7 +79,8 @@ class WGAN_GP(GAN):
     """wgan_gp.py:19-20."""
     return -fake_output.mean()
 
-  def _critic_forward(self, st, real, z, alpha, shifts, slot):
+  def _critic_forward(self, st, real, z, alpha, shifts, slot,
+                      real_cached=False):
     """Steps 1-5 of the critic schedule; leaves g in st['critic'].gin."""
     net_d = self.discriminator.net
     B = real.shape[0]
@@ -81,7 +91,7 @@ class WGAN_GP(GAN):
     fake = st['gws'].forward(z)
     _lib.call('cg_interp_pack', nets._p(real), nets._p(fake), nets._p(alpha),
               nets._p(st['dws'].act[0]), B, lay.lin, lay.cin, lay.cin, lay.cinp,
-              lay.cinp, s)
+              lay.cinp, 0 if real_cached else 1, s)
     plan.forward()
     plan.backward_chain()
     n = lay.lin * lay.cinp
@@ -93,7 +103,8 @@ class WGAN_GP(GAN):
               nets._p(st['loss'][slot]), B, s)
     return fake
 
-  def _train_discriminator(self, inputs, r=None, slot=0):
+  def _train_discriminator(self, inputs, r=None, slot=0, real_cached=False,
+                           lr_t_dev=None):
     """wgan_gp.py:64-80."""
     real = self._to_device(inputs)
     B = real.shape[0]
@@ -104,6 +115,10 @@ class WGAN_GP(GAN):
       z = self.get_noise(B)
       alpha = self._streams.alpha(B)
       shifts = self._streams.shifts(3)
+    elif 'shifts_dev' in r:  # graph replay: draws staged in device memory
+      z = self.get_noise(B)
+      alpha = self._streams.alpha(B)
+      shifts = r['shifts_dev']
     else:
       z = self._to_device(r['z'])
       alpha = self._to_device(r['alpha'])
@@ -112,7 +127,7 @@ class WGAN_GP(GAN):
           torch.as_tensor(r['shifts_fake'], dtype=torch.int32),
           torch.as_tensor(r['shifts_inter'], dtype=torch.int32)
       ], dim=1)
-    self._critic_forward(st, real, z, alpha, shifts, slot)
+    self._critic_forward(st, real, z, alpha, shifts, slot, real_cached)
     plan = st['critic']
     s = nets._stream()
     n = lay.lin * lay.cinp
@@ -123,10 +138,11 @@ class WGAN_GP(GAN):
     net_d.params.grad.zero_()
     plan.weight_grads(bias_rows=2 * B)
     self._sync.all_reduce(net_d.params.grad)
-    self.dis_optimizer.update(self.discriminator, self._sync.grad_scale)
+    self.dis_optimizer.update(self.discriminator, self._sync.grad_scale,
+                              lr_t_dev=lr_t_dev)
     return st['loss'][slot, 0], st['gp'][slot]
 
-  def _train_generator(self, inputs, r=None):
+  def _train_generator(self, inputs, r=None, lr_t_dev=None):
     """wgan_gp.py:22-36."""
     real = self._to_device(inputs)
     B = real.shape[0]
@@ -137,6 +153,9 @@ class WGAN_GP(GAN):
     if r is None:
       z = self.get_noise(B)
       shifts = self._streams.shifts(1)
+    elif 'shifts_dev' in r:
+      z = self.get_noise(B)
+      shifts = r['shifts_dev']
     else:
       z = self._to_device(r['z'])
       shifts = torch.as_tensor(r['shifts'], dtype=torch.int32).reshape(4, 1)
@@ -152,26 +171,93 @@ class WGAN_GP(GAN):
     net_g.params.grad.zero_()
     st['gws'].backward(plan.gin)
     self._sync.all_reduce(net_g.params.grad)
-    self.gen_optimizer.update(self.generator, self._sync.grad_scale)
+    self.gen_optimizer.update(self.generator, self._sync.grad_scale,
+                              lr_t_dev=lr_t_dev)
     metrics = self.metrics(real, fake, fake_pitch=net_g.Cp)
     return st['gen_loss'][0], metrics
+
+  def _train_body(self, real, rand=None, lr_dev=None):
+    """The n_critic + 1 updates of one train() (wgan_gp.py:82-95)."""
+    B = real.shape[0]
+    st = self._get_state(B)
+    for i in range(self.n_critic):
+      # the bf16 copy of `real` in X0[0:B] survives a critic step (only the
+      # x^ segment is overwritten), so it is converted once per train()
+      self._train_discriminator(
+          real, None if rand is None else rand['critic'][i], slot=i,
+          real_cached=i > 0,
+          lr_t_dev=None if lr_dev is None else lr_dev[i:])
+    gen_loss, metrics = self._train_generator(
+        real, None if rand is None else rand['gen'],
+        lr_t_dev=None if lr_dev is None else lr_dev[self.n_critic:])
+    dis_loss = st['loss'][:self.n_critic, 0].mean()
+    gradient_penalty = st['gp'][:self.n_critic].mean()
+    return gen_loss.clone(), dis_loss, gradient_penalty, metrics
+
+  def _capture(self, real, st):
+    """Capture one train() into a hipGraph.  Host-drawn inputs of a replay
+    (phase shifts, Adam step sizes) travel through pinned staging buffers that
+    the graph copies to the device first; z / alpha come from the (graph-
+    registered) device generator."""
+    dev = self.device
+    n = self.n_critic
+    g = dict(
+        real=torch.empty_like(real),
+        shifts_host=torch.zeros(n * 12 + 4, dtype=torch.int32).pin_memory(),
+        shifts_dev=torch.zeros(n * 12 + 4, dtype=torch.int32, device=dev),
+        lr_host=torch.zeros(n + 1, dtype=torch.float32).pin_memory(),
+        lr_dev=torch.zeros(n + 1, dtype=torch.float32, device=dev))
+    g['real'].copy_(real)
+    rand = dict(
+        critic=[dict(shifts_dev=g['shifts_dev'][12 * i:12 * i + 12].view(4, 3))
+                for i in range(n)],
+        gen=dict(shifts_dev=g['shifts_dev'][12 * n:].view(4, 1)))
+    graph = torch.cuda.CUDAGraph()
+    graph.register_generator_state(self._streams.local)
+    it_d, it_g = self.dis_optimizer.iterations, self.gen_optimizer.iterations
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+      g['shifts_dev'].copy_(g['shifts_host'], non_blocking=True)
+      g['lr_dev'].copy_(g['lr_host'], non_blocking=True)
+      g['out'] = self._train_body(g['real'], rand, g['lr_dev'])
+    # capture only records: undo the host-side step counters it advanced
+    self.dis_optimizer.iterations, self.gen_optimizer.iterations = it_d, it_g
+    g['graph'] = graph
+    return g
+
+  def _train_graphed(self, real, st):
+    g = st.get('graph')
+    if g is None:
+      g = st['graph'] = self._capture(real, st)
+    n = self.n_critic
+    if g['real'].data_ptr() != real.data_ptr():
+      g['real'].copy_(real)
+    sh = g['shifts_host']
+    for i in range(n):
+      sh[12 * i:12 * i + 12] = self._streams.shifts(3).reshape(-1)
+    sh[12 * n:] = self._streams.shifts(1).reshape(-1)
+    for i in range(n):
+      g['lr_host'][i] = self.dis_optimizer.lr_t(self.dis_optimizer.iterations +
+                                                i + 1)
+    g['lr_host'][n] = self.gen_optimizer.lr_t(self.gen_optimizer.iterations + 1)
+    g['graph'].replay()
+    self.dis_optimizer.iterations += n
+    self.gen_optimizer.iterations += 1
+    return g['out']
 
   def train(self, inputs, rand=None):
     """wgan_gp.py:82-95: n_critic critic updates on the SAME batch, then one
     generator update.  Returns (gen_loss, dis_loss, gradient_penalty, metrics)
     as 0-d device tensors (no host sync inside).  `rand` optionally injects the
-    random draws (same structure as oracle.draw_randomness) for parity tests."""
+    random draws (same structure as oracle.draw_randomness) for parity tests.
+    After two eager calls per batch size the step replays as one hipGraph."""
     real = self._to_device(inputs)
-    B = real.shape[0]
-    st = self._get_state(B)
-    for i in range(self.n_critic):
-      self._train_discriminator(
-          real, None if rand is None else rand['critic'][i], slot=i)
-    gen_loss, metrics = self._train_generator(
-        real, None if rand is None else rand['gen'])
-    dis_loss = st['loss'][:self.n_critic, 0].mean()
-    gradient_penalty = st['gp'][:self.n_critic].mean()
-    return gen_loss.clone(), dis_loss, gradient_penalty, metrics
+    if rand is None and self._use_graph:
+      st = self._get_state(real.shape[0])
+      st['calls'] = st.get('calls', 0) + 1
+      if st['calls'] > _GRAPH_WARMUP_CALLS:
+        return self._train_graphed(real, st)
+    return self._train_body(real, rand)
 
   def validate(self, inputs, rand=None):
     """gan.py:87-90 / :58-70 with the WGAN-GP loss (inner-gradient penalty, no

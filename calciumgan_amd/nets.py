@@ -109,6 +109,28 @@ class PackedOperand(object):
       _lib.call('cg_pack_weights', ctypes.byref(d), st)
 
 
+class PackPlan(object):
+  """All PackedOperands of one model packed by ONE kernel launch
+  (cg_pack_batched): the descriptor table lives in device memory."""
+
+  def __init__(self, operands, device):
+    lib = _lib.load()
+    descs = [d for op in operands for d in op.descs]
+    self.n = len(descs)
+    arr = (PackDesc * self.n)(*descs)
+    self.blocks = lib.cg_pack_plan_build(arr, self.n, None, 0)
+    if self.blocks < 0:
+      raise ValueError('bad packing geometry')
+    nbytes = lib.cg_pack_plan_bytes(self.n, self.blocks)
+    host = torch.zeros(nbytes, dtype=torch.uint8)
+    lib.cg_pack_plan_build(arr, self.n, host.data_ptr(), nbytes)
+    self.dev = host.to(device)
+    self._keep = operands
+
+  def run(self):
+    _lib.call('cg_pack_batched', _p(self.dev), self.n, self.blocks, _stream())
+
+
 def _transpose_phases(k, pad_left):
   """Tap walk of the two output phases of a stride-2 transposed convolution
   (SURVEY Appendix A.2): out[2u+p] = sum_jj src[u + off_p + jj] * W[tap0_p - 2jj].
@@ -271,13 +293,13 @@ class DiscriminatorNet(object):
       self.w_dgrad.append(
           PackedOperand(W, [(t0, -2, ci * co, 1, co) for t0, _ in phases], co,
                         ci, lay.coutp, ck, self.k // 2))
+    self._pack_plan = PackPlan(self.w_fwd + self.w_dgrad, device)
     self.repack()
     self._ws = {}
 
   # -- parameters ---------------------------------------------------------
   def repack(self):
-    for op in self.w_fwd + self.w_dgrad:
-      op.repack()
+    self._pack_plan.run()
 
   @property
   def dense_w(self):
@@ -524,12 +546,14 @@ class GeneratorNet(object):
                                self.Cp, ck, 1)
     self.w_out_t = PackedOperand(Wo, [(0, 1, 0, 1, self.C)], self.C, self.C,
                                  self.Cp, ck, 1)
+    self._pack_plan = PackPlan(
+        [self.w_in, self.w_out, self.w_out_t] + self.w_fwd + self.w_dgrad,
+        device)
     self.repack()
     self._ws = {}
 
   def repack(self):
-    for op in [self.w_in, self.w_out, self.w_out_t] + self.w_fwd + self.w_dgrad:
-      op.repack()
+    self._pack_plan.run()
 
   def workspace(self, B):
     ws = self._ws.get(B)
@@ -659,11 +683,17 @@ class _GenWorkspace(object):
     _lib.call('cg_colsum', _p(self.dy[0]), _p(G[1]), self.B, nflat, nflat, st)
 
 
+def adam_lr_t(step, lr, beta1=0.9, beta2=0.999):
+  """Keras Adam's bias-corrected step size at 1-based iteration `step`."""
+  return lr * math.sqrt(1.0 - beta2**step) / (1.0 - beta1**step)
+
+
 def adam_update(params, step, lr, grad_scale=1.0, beta1=0.9, beta2=0.999,
-                eps=1e-7):
+                eps=1e-7, lr_t_dev=None):
   """tf.keras.optimizers.Adam dense update (gan/algorithms/optimizer.py:9,
-  :31-34); `step` is the 1-based iteration count."""
-  lr_t = lr * math.sqrt(1.0 - beta2**step) / (1.0 - beta1**step)
+  :31-34); `step` is the 1-based iteration count.  lr_t_dev (device scalar)
+  overrides the host-computed step size (captured-graph replay)."""
+  lr_t = adam_lr_t(step, lr, beta1, beta2)
   _lib.call('cg_adam', _p(params.data), _p(params.grad), _p(params.m),
             _p(params.v), params.numel, lr_t, beta1, beta2, eps, grad_scale,
-            _stream())
+            _p(lr_t_dev), _stream())

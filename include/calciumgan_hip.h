@@ -100,6 +100,16 @@ typedef struct cg_pack_desc {
   int C_real, N_real, Cx, CK;
 } cg_pack_desc;
 int cg_pack_weights(const cg_pack_desc* d, void* stream);
+/* Batched form (one launch for all operands of a model).  Host side:
+ *   blocks = cg_pack_plan_build(descs, n, NULL, 0);            (sizing pass)
+ *   bytes  = cg_pack_plan_bytes(n, blocks);
+ *   cg_pack_plan_build(descs, n, host_buf, bytes);             (fills host_buf)
+ * copy host_buf to device memory once, then after every optimizer update
+ *   cg_pack_batched(dev_plan, n, blocks, stream). */
+long long cg_pack_plan_bytes(int n, long long total_blocks);
+long long cg_pack_plan_build(const cg_pack_desc* descs, int n, void* host_buf,
+                             long long host_bytes);
+int cg_pack_batched(const void* dev_plan, int n, long long blocks, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Weight gradient of the sliding-window convolution (f32 accumulate, f32
@@ -177,6 +187,7 @@ int cg_unshuffle_mask(const void* e /*bf16 [nB][w][Cp]*/, const void* h,
  * C valid channels), x0 bf16 [3B][L][Cp]. */
 int cg_interp_pack(const float* real, const float* fake, const float* alpha,
                    void* x0, int B, int L, int C, int Cr, int Cf, int Cp,
+                   int write_real /* 0: x0[0:B] already holds bf16(real) */,
                    void* stream);
 /* dst bf16 [rows][Cp] = src f32 [rows][Cs] (C valid channels), pad zero */
 int cg_cast_pad(const float* src, void* dst, long long rows, int C, int Cs,
@@ -215,6 +226,8 @@ int cg_lrelu_bwd(const void* dh, const void* h, void* dpre, long long n,
  * ------------------------------------------------------------------------- */
 int cg_adam(float* p, const float* grad, float* m, float* v, long long n,
             float lr_t, float beta1, float beta2, float eps, float grad_scale,
+            const float* lr_t_dev /* device scalar overriding lr_t, or NULL
+                                     (lets a captured hipGraph vary the step) */,
             void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -402,7 +402,7 @@ def test_wgan_gp_elementwise_kernels():
   x0 = torch.zeros(3 * B, L, cp, dtype=BF16, device=H.DEV)
   real_d, fake_d, alpha_d = real.to(H.DEV), fake_p.to(H.DEV), alpha.to(H.DEV)
   _lib.call('cg_interp_pack', H.p(real_d), H.p(fake_d), H.p(alpha_d), H.p(x0),
-            B, L, C, C, cp, cp, H.stream())
+            B, L, C, C, cp, cp, 1, H.stream())
   H.sync()
   got = x0.float().cpu()
   inter = O.interpolation(real, fake, alpha)
@@ -457,7 +457,7 @@ def test_adam_colsum_sigmoid_lrelu_metrics():
   import math
   lr_t = 1e-3 * math.sqrt(1 - 0.999**3) / (1 - 0.9**3)
   _lib.call('cg_adam', H.p(pd), H.p(gd), H.p(md), H.p(vd), n, lr_t, 0.9, 0.999,
-            1e-7, 0.5, H.stream())
+            1e-7, 0.5, None, H.stream())
   H.sync()
   np.testing.assert_allclose(pd.cpu().numpy(), pr.float().numpy(), rtol=1e-6,
                              atol=1e-7)

@@ -315,3 +315,30 @@ def test_hip_step_against_committed_golden():
   gr = _flat([d['ggrad%02d' % i] for i in range(24)])
   assert abs(np.linalg.norm(gh) / np.linalg.norm(gr) - 1) < 2e-2
   assert gh @ gr / (np.linalg.norm(gh) * np.linalg.norm(gr)) > 0.985
+
+
+def test_graph_replay_matches_eager():
+  """train() replayed as a captured hipGraph (after 2 eager warm-up calls)
+  follows the eager path: same random streams, same Keras-Adam step sizes
+  (device scalar), same losses / weights up to f32-atomic ordering noise."""
+  outs = {}
+  for use_graph in (False, True):
+    hp, gen, dis, gan, real, B = _build('tiny')
+    gan._use_graph = use_graph
+    losses = []
+    for step in range(6):
+      o = gan.train(real)
+      losses.append([float(o[0]), float(o[1]), float(o[2])] +
+                    [float(o[3][k]) for k in sorted(o[3])])
+    torch.cuda.synchronize()
+    if use_graph:
+      assert gan._get_state(B).get('graph') is not None
+    assert gan.dis_optimizer.iterations == 30
+    assert gan.gen_optimizer.iterations == 6
+    outs[use_graph] = (np.array(losses), _flat(dis.get_weights()),
+                       _flat(gen.get_weights()))
+  np.testing.assert_allclose(outs[True][0], outs[False][0], rtol=2e-2,
+                             atol=2e-3)
+  for i in (1, 2):
+    d = np.linalg.norm(outs[True][i] - outs[False][i])
+    assert d / np.linalg.norm(outs[False][i]) < 1e-3
