@@ -99,12 +99,15 @@ def main():
   ap.add_argument('--cpu_batch', type=int, default=8)
   ap.add_argument('--cpu_steps', type=int, default=3)
   ap.add_argument('--no_kernel_timing', action='store_true')
+  ap.add_argument('--backend', default='nccl',
+                  help="torch.distributed backend ('nccl' = RCCL; 'gloo' only "
+                  'for single-GPU rehearsals of the multi-rank path)')
   args = ap.parse_args()
 
   from calciumgan_amd import nets, parallel
   world = parallel.env_world()
   if world > 1:
-    parallel.init_process_group('nccl')
+    parallel.init_process_group(args.backend)
   else:
     torch.cuda.set_device(0)
   rank = parallel.rank()

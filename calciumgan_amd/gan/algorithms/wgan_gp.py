@@ -29,9 +29,9 @@ from ... import nets
 from .gan import GAN
 from .registry import register
 
-# Whole-step hipGraph capture (single-process runs): the ~370 launches of one
-# train() replay as one graph, removing launch gaps.  CALCIUMGAN_GRAPH=0
-# disables it; it is never used under data parallelism (RCCL calls stay eager).
+# hipGraph capture of train(): the ~370 launches of one step replay as
+# n_critic + 2 graphs cut at the gradient all-reduces (the RCCL calls stay
+# eager between replays), removing launch gaps.  CALCIUMGAN_GRAPH=0 disables it.
 _GRAPH_WARMUP_CALLS = 2
 
 
@@ -46,8 +46,7 @@ class WGAN_GP(GAN):
     if self.conv2d:
       raise ValueError('calciumgan_amd: conv2d models are out of scope')
     self._state = {}
-    self._use_graph = (os.environ.get('CALCIUMGAN_GRAPH', '1') != '0' and
-                       self._sync.world == 1)
+    self._use_graph = os.environ.get('CALCIUMGAN_GRAPH', '1') != '0'
 
   # -- per-batch-size state ---------------------------------------------------
   def _get_state(self, B):
@@ -103,10 +102,10 @@ class WGAN_GP(GAN):
               nets._p(st['loss'][slot]), B, s)
     return fake
 
-  def _train_discriminator(self, inputs, r=None, slot=0, real_cached=False,
-                           lr_t_dev=None):
-    """wgan_gp.py:64-80."""
-    real = self._to_device(inputs)
+  # -- the step, cut at the all-reduce points ---------------------------------
+  def _critic_compute(self, real, r=None, slot=0, real_cached=False):
+    """wgan_gp.py:64-80 up to (not including) the optimizer update: leaves the
+    critic gradients in discriminator.net.params.grad."""
     B = real.shape[0]
     st = self._get_state(B)
     net_d = self.discriminator.net
@@ -137,14 +136,23 @@ class WGAN_GP(GAN):
     plan.jvp_forward()
     net_d.params.grad.zero_()
     plan.weight_grads(bias_rows=2 * B)
-    self._sync.all_reduce(net_d.params.grad)
+
+  def _critic_apply(self, lr_t_dev=None):
     self.dis_optimizer.update(self.discriminator, self._sync.grad_scale,
                               lr_t_dev=lr_t_dev)
+
+  def _train_discriminator(self, inputs, r=None, slot=0, real_cached=False,
+                           lr_t_dev=None):
+    """wgan_gp.py:64-80."""
+    real = self._to_device(inputs)
+    st = self._get_state(real.shape[0])
+    self._critic_compute(real, r, slot, real_cached)
+    self._sync.all_reduce(self.discriminator.net.params.grad)
+    self._critic_apply(lr_t_dev)
     return st['loss'][slot, 0], st['gp'][slot]
 
-  def _train_generator(self, inputs, r=None, lr_t_dev=None):
-    """wgan_gp.py:22-36."""
-    real = self._to_device(inputs)
+  def _gen_compute(self, real, r=None):
+    """wgan_gp.py:22-36 up to the optimizer update."""
     B = real.shape[0]
     st = self._get_state(B)
     net_g, net_d = self.generator.net, self.discriminator.net
@@ -170,35 +178,76 @@ class WGAN_GP(GAN):
     plan.backward_chain()
     net_g.params.grad.zero_()
     st['gws'].backward(plan.gin)
-    self._sync.all_reduce(net_g.params.grad)
+
+  def _gen_apply(self, real, lr_t_dev=None):
+    st = self._get_state(real.shape[0])
     self.gen_optimizer.update(self.generator, self._sync.grad_scale,
                               lr_t_dev=lr_t_dev)
-    metrics = self.metrics(real, fake, fake_pitch=net_g.Cp)
+    return self.metrics(real, st['gws'].fake, fake_pitch=self.generator.net.Cp)
+
+  def _train_generator(self, inputs, r=None, lr_t_dev=None):
+    """wgan_gp.py:22-36."""
+    real = self._to_device(inputs)
+    st = self._get_state(real.shape[0])
+    self._gen_compute(real, r)
+    self._sync.all_reduce(self.generator.net.params.grad)
+    metrics = self._gen_apply(real, lr_t_dev)
     return st['gen_loss'][0], metrics
 
-  def _train_body(self, real, rand=None, lr_dev=None):
-    """The n_critic + 1 updates of one train() (wgan_gp.py:82-95)."""
-    B = real.shape[0]
-    st = self._get_state(B)
-    for i in range(self.n_critic):
-      # the bf16 copy of `real` in X0[0:B] survives a critic step (only the
-      # x^ segment is overwritten), so it is converted once per train()
-      self._train_discriminator(
-          real, None if rand is None else rand['critic'][i], slot=i,
-          real_cached=i > 0,
-          lr_t_dev=None if lr_dev is None else lr_dev[i:])
-    gen_loss, metrics = self._train_generator(
-        real, None if rand is None else rand['gen'],
-        lr_t_dev=None if lr_dev is None else lr_dev[self.n_critic:])
-    dis_loss = st['loss'][:self.n_critic, 0].mean()
-    gradient_penalty = st['gp'][:self.n_critic].mean()
-    return gen_loss.clone(), dis_loss, gradient_penalty, metrics
+  def _segments(self, real, rand=None, lr_dev=None, out=None):
+    """One train() (wgan_gp.py:82-95) as n_critic + 2 launch segments cut at
+    the gradient all-reduces: segment i ends with the gradients of update i
+    complete; the all-reduce of (flat_grad) follows it.  Returns
+    [(callable, flat_grad_to_reduce_or_None)]; the last callable stores the
+    step's outputs in out['value']."""
+    n = self.n_critic
+    st = self._get_state(real.shape[0])
+    out = {} if out is None else out
+    lr = (lambda i: None) if lr_dev is None else (lambda i: lr_dev[i:])
+    rc = (lambda i: None) if rand is None else (lambda i: rand['critic'][i])
+    d_grad = self.discriminator.net.params.grad
+    g_grad = self.generator.net.params.grad
+
+    def critic_seg(i):
+      def run():
+        if i > 0:
+          self._critic_apply(lr(i - 1))
+        # the bf16 copy of `real` in X0[0:B] survives a critic step (only the
+        # x^ segment is overwritten): converted once per train()
+        self._critic_compute(real, rc(i), slot=i, real_cached=i > 0)
+      return run
+
+    def gen_seg():
+      if n > 0:
+        self._critic_apply(lr(n - 1))
+      self._gen_compute(real, None if rand is None else rand['gen'])
+
+    def last_seg():
+      metrics = self._gen_apply(real, lr(n))
+      dis_loss = st['loss'][:n, 0].mean()
+      gradient_penalty = st['gp'][:n].mean()
+      out['value'] = (st['gen_loss'][0].clone(), dis_loss, gradient_penalty,
+                      metrics)
+
+    segs = [(critic_seg(i), d_grad) for i in range(n)]
+    segs.append((gen_seg, g_grad))
+    segs.append((last_seg, None))
+    return segs, out
+
+  def _train_body(self, real, rand=None):
+    segs, out = self._segments(real, rand)
+    for fn, grad in segs:
+      fn()
+      if grad is not None:
+        self._sync.all_reduce(grad)
+    return out['value']
 
   def _capture(self, real, st):
-    """Capture one train() into a hipGraph.  Host-drawn inputs of a replay
-    (phase shifts, Adam step sizes) travel through pinned staging buffers that
-    the graph copies to the device first; z / alpha come from the (graph-
-    registered) device generator."""
+    """Capture one train() as hipGraphs, one per segment (RCCL all-reduces stay
+    eager between replays).  Host-drawn inputs of a replay (phase shifts, Adam
+    step sizes) travel through pinned staging buffers that the first graph
+    copies to the device; z / alpha come from the graph-registered device
+    generator."""
     dev = self.device
     n = self.n_critic
     g = dict(
@@ -212,17 +261,25 @@ class WGAN_GP(GAN):
         critic=[dict(shifts_dev=g['shifts_dev'][12 * i:12 * i + 12].view(4, 3))
                 for i in range(n)],
         gen=dict(shifts_dev=g['shifts_dev'][12 * n:].view(4, 1)))
-    graph = torch.cuda.CUDAGraph()
-    graph.register_generator_state(self._streams.local)
+    segs, out = self._segments(g['real'], rand, g['lr_dev'])
     it_d, it_g = self.dis_optimizer.iterations, self.gen_optimizer.iterations
+    graphs = []
+    pool = None
     torch.cuda.synchronize()
-    with torch.cuda.graph(graph):
-      g['shifts_dev'].copy_(g['shifts_host'], non_blocking=True)
-      g['lr_dev'].copy_(g['lr_host'], non_blocking=True)
-      g['out'] = self._train_body(g['real'], rand, g['lr_dev'])
+    for k, (fn, grad) in enumerate(segs):
+      graph = torch.cuda.CUDAGraph()
+      graph.register_generator_state(self._streams.local)
+      with torch.cuda.graph(graph, pool=pool):
+        if k == 0:
+          g['shifts_dev'].copy_(g['shifts_host'], non_blocking=True)
+          g['lr_dev'].copy_(g['lr_host'], non_blocking=True)
+        fn()
+      pool = graph.pool()
+      graphs.append((graph, grad))
     # capture only records: undo the host-side step counters it advanced
     self.dis_optimizer.iterations, self.gen_optimizer.iterations = it_d, it_g
-    g['graph'] = graph
+    g['graphs'] = graphs
+    g['out'] = out['value']
     return g
 
   def _train_graphed(self, real, st):
@@ -240,7 +297,10 @@ class WGAN_GP(GAN):
       g['lr_host'][i] = self.dis_optimizer.lr_t(self.dis_optimizer.iterations +
                                                 i + 1)
     g['lr_host'][n] = self.gen_optimizer.lr_t(self.gen_optimizer.iterations + 1)
-    g['graph'].replay()
+    for graph, grad in g['graphs']:
+      graph.replay()
+      if grad is not None:
+        self._sync.all_reduce(grad)
     self.dis_optimizer.iterations += n
     self.gen_optimizer.iterations += 1
     return g['out']
@@ -250,7 +310,7 @@ class WGAN_GP(GAN):
     generator update.  Returns (gen_loss, dis_loss, gradient_penalty, metrics)
     as 0-d device tensors (no host sync inside).  `rand` optionally injects the
     random draws (same structure as oracle.draw_randomness) for parity tests.
-    After two eager calls per batch size the step replays as one hipGraph."""
+    After two eager calls per batch size the step replays as hipGraphs."""
     real = self._to_device(inputs)
     if rand is None and self._use_graph:
       st = self._get_state(real.shape[0])

@@ -32,8 +32,10 @@ def init_process_group(backend=None):
     return
   if backend is None:
     backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-  if backend == 'nccl':
-    torch.cuda.set_device(env_local_rank())
+  if torch.cuda.is_available():
+    # one GPU per rank; the modulo only matters for single-GPU rehearsals of
+    # the multi-rank path with the gloo backend
+    torch.cuda.set_device(env_local_rank() % torch.cuda.device_count())
   dist.init_process_group(backend=backend)
 
 

@@ -1,15 +1,27 @@
 export TMPDIR=/tmp
-ARGS="conv 2 24 384 512 128 192 32 0 1 0 0"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc1 -- python3 tools/bench_conv.py $ARGS > gpurun_out/pmc1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_VMEM --kernel-trace --output-format csv -d gpurun_out/pmc2 -- python3 tools/bench_conv.py $ARGS > gpurun_out/pmc2.log 2>&1
-python3 - <<'PY'
+run() {
+tag=$1; shift
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 tools/bench_conv.py "$@" > gpurun_out/pmc_$tag.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmcb_$tag -- python3 tools/bench_conv.py "$@" >> gpurun_out/pmc_$tag.log 2>&1
+python3 - <<PY
 import csv, glob, collections
-for d in ('pmc1','pmc2'):
+res={}
+for d in ('pmc_$tag','pmcb_$tag'):
     for f in glob.glob('gpurun_out/%s/*/*counter_collection.csv'%d):
         agg=collections.defaultdict(lambda:[0,0.0])
         for r in csv.DictReader(open(f)):
-            if 'swconv' not in r['Kernel_Name']: continue
+            if 'swconv' not in r['Kernel_Name'] and 'wgrad' not in r['Kernel_Name']: continue
             a=agg[r['Counter_Name']]; a[0]+=1; a[1]+=float(r['Counter_Value'])
-        for k,(n,v) in sorted(agg.items()):
-            print(d,k,n,v/n)
+        for k,(n,v) in agg.items(): res[k]=v/n
+    for f in glob.glob('gpurun_out/%s/*/*kernel_trace.csv'%d):
+        ds=[float(r['End_Timestamp'])-float(r['Start_Timestamp']) for r in csv.DictReader(open(f)) if 'swconv' in r['Kernel_Name'] or 'wgrad' in r['Kernel_Name']]
+        res['dur_us_'+d[:4]]=sum(ds)/len(ds)/1e3
+print('$tag', {k:round(v,1) for k,v in sorted(res.items())})
+wc=res['SQ_WAVE_CYCLES']
+print('  per wave-cycle: active %.2f wait_any %.2f wait_inst %.2f | mfma_quad %.2f lds_active/mfma_cycles %.2f conflicts/lds %.3f valu/mfma %.2f lds/mfma %.2f' % (res['SQ_ACTIVE_INST_ANY']/wc, res['SQ_WAIT_ANY']/wc, res['SQ_WAIT_INST_ANY']/wc, res['SQ_INSTS_MFMA']*4/wc, res['SQ_LDS_IDX_ACTIVE']/ (res['SQ_INSTS_MFMA']*16/4), res['SQ_LDS_BANK_CONFLICT']/res['SQ_LDS_IDX_ACTIVE'], (res['SQ_INSTS_VALU']-res['SQ_INSTS_MFMA'])/res['SQ_INSTS_MFMA'], res['SQ_INSTS_LDS']/res['SQ_INSTS_MFMA']))
 PY
+}
+run r2mt2 conv 2 24 384 512 128 192 32 2 1 0 0
+run r2mt4 conv 2 24 384 512 128 192 32 0 1 0 0
+run r1mt4 conv 1 12 384 256 192 128 64 0 0 0 0
+run wg wgrad 2 24 384 512 128 192
