@@ -56,6 +56,7 @@ class WgradDesc(C.Structure):
       ('taps', c_i), ('stride', c_i), ('off', c_i),
       ('Cx_real', c_i), ('Cg_real', c_i),
       ('nsplit', c_i),
+      ('tile_rows', c_i),
   ]
 
 

@@ -576,11 +576,12 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   if (ldsA_bytes < (size_t)kScratchBytes) ldsA_bytes = kScratchBytes;
   ldsA_bytes = (ldsA_bytes + 15) / 16 * 16;
   a.ldsA_elems = (int)(ldsA_bytes / 2);
-  // weight-stage width: 128 K-elements when two workgroups still fit a CU with
-  // it (or when nothing would), else 64
-  const size_t half_cu = 80 * 1024;
+  // weight-stage width: the narrow (64-wide) stage when it lets one more
+  // workgroup fit on a CU (occupancy beats stage length: measured), else the
+  // wide (128-wide) one
+  const size_t cu_lds = 160 * 1024;
   int ks = 4;
-  if (ldsA_bytes + ldsB_bytes(4) > half_cu && ldsA_bytes + ldsB_bytes(2) <= half_cu)
+  if (cu_lds / (ldsA_bytes + ldsB_bytes(2)) > cu_lds / (ldsA_bytes + ldsB_bytes(4)))
     ks = 2;
   if (d->stage_ksteps == 2 || d->stage_ksteps == 4) ks = d->stage_ksteps;
   const size_t lds = ldsA_bytes + ldsB_bytes(ks);

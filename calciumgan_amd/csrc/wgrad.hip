@@ -49,14 +49,14 @@ __device__ __forceinline__ bf16x8 join(s16x4 lo, s16x4 hi) {
 
 // MFMA work of one staged tile: every wave reads its transposed fragments from
 // the row-major LDS images and accumulates its taps.
-template <int R, int TPW, bool ROWSPLIT>
+template <int R, int TPW, bool ROWSPLIT, int TT>
 __device__ __forceinline__ void wgrad_compute(const WgradArgs& a,
                                               const uint16_t* ldsX,
                                               const uint16_t* ldsG,
                                               int regionRows, int wave, int g4,
                                               int q, int p,
                                               f32x4 (&acc)[TPW][2][4]) {
-  constexpr int KSTEPS = ROWSPLIT ? 1 : 2;
+  constexpr int KSTEPS = ROWSPLIT ? 1 : TT / 32;
 #pragma unroll
   for (int kstep = 0; kstep < KSTEPS; ++kstep) {
     const int rbase = ROWSPLIT ? wave * 32 : kstep * 32;
@@ -98,11 +98,11 @@ __device__ __forceinline__ void wgrad_compute(const WgradArgs& a,
 // split the staged rows (TT = 256) instead of the taps (TT = 64).  PIPE: one
 // sample per tile (nseg == 1): tiles are double-buffered in LDS and the next
 // tile's global loads are issued before the current tile's MFMAs.
-template <int R, int TPW, bool ROWSPLIT, bool PIPE>
+template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT>
 __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int TT = ROWSPLIT ? 256 : 64;
-  constexpr int NG = TT * 8 / 512;  // g pieces per thread (1 or 4)
+  static_assert(!ROWSPLIT || TT == 256, "row-split tiles are 256 rows");
+  constexpr int NG = TT * 8 / 512;  // g pieces per thread (1, 2 or 4)
   const int regionRows = a.nseg * a.WR;
   const int bufX = R * regionRows * kPitchX;  // elements
   const int bufG = TT * kPitchG;
@@ -136,6 +136,10 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
     const int xrowA = tid >> 2;          // piece 0
     const int xrowB = (tid + 512) >> 2;  // piece 1 (if tid + 512 < totalX)
     const bool hasB = tid + 512 < totalX;
+    const int xrowC = (tid + 1024) >> 2;  // piece 2 (128-row tiles only)
+    const bool hasC = TT == 128 && tid + 1024 < totalX;
+    const int rhoC = (R == 2 && xrowC >= a.WR) ? 1 : 0;
+    const int dC = R * (xrowC - rhoC * a.WR) + rhoC;
     const int rhoA = (R == 2 && xrowA >= a.WR) ? 1 : 0;
     const int rhoB = (R == 2 && xrowB >= a.WR) ? 1 : 0;
     const int dA = R * (xrowA - rhoA * a.WR) + rhoA;  // source row delta
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
     const int gq8 = tid & 7;
     const int gc = cg0 + gq8 * 8;
     const int grow = tid >> 3;  // + 64 * j
-    uint4 xa, xb, gr[NG];
+    uint4 xa, xb, xc2, gr[NG];
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
 
     auto load_tile = [&](int tile) {
@@ -155,6 +159,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
       const int srow0 = R * u0 + a.off;
       xa = zero;
       xb = zero;
+      xc2 = zero;
       if (xc < a.Cx) {
         int sr = srow0 + dA;
         if (sr >= 0 && sr < a.Lx) {
@@ -165,6 +170,11 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
         if (hasB && sr >= 0 && sr < a.Lx) {
           if (a.shifts) sr = shuffle_src(sr, sft, a.Lx);
           xb = *reinterpret_cast<const uint4*>(xbase + (long long)sr * a.Cx);
+        }
+        sr = srow0 + dC;
+        if (hasC && sr >= 0 && sr < a.Lx) {
+          if (a.shifts) sr = shuffle_src(sr, sft, a.Lx);
+          xc2 = *reinterpret_cast<const uint4*>(xbase + (long long)sr * a.Cx);
         }
       }
 #pragma unroll
@@ -180,6 +190,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
       uint16_t* lg = base + bufX;
       *reinterpret_cast<uint4*>(lx + xrowA * kPitchX + xq8 * 8) = xa;
       if (hasB) *reinterpret_cast<uint4*>(lx + xrowB * kPitchX + xq8 * 8) = xb;
+      if (hasC) *reinterpret_cast<uint4*>(lx + xrowC * kPitchX + xq8 * 8) = xc2;
 #pragma unroll
       for (int j = 0; j < NG; ++j)
         *reinterpret_cast<uint4*>(lg + (grow + 64 * j) * kPitchG + gq8 * 8) =
@@ -198,8 +209,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
       const bool more = tile + stride < a.ntiles;
       if (more) load_tile(tile + stride);
       const uint16_t* base = lds + cur * (bufX + bufG);
-      wgrad_compute<R, TPW, ROWSPLIT>(a, base, base + bufX, regionRows, wave, g4,
-                                      q, p, acc);
+      wgrad_compute<R, TPW, ROWSPLIT, TT>(a, base, base + bufX, regionRows, wave,
+                                          g4, q, p, acc);
       if (more) {
         store_tile(lds + (cur ^ 1) * (bufX + bufG));
         __syncthreads();
@@ -246,8 +257,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
         *reinterpret_cast<uint4*>(ldsG + row * kPitchG + q8 * 8) = v;
       }
       __syncthreads();
-      wgrad_compute<R, TPW, ROWSPLIT>(a, ldsX, ldsG, regionRows, wave, g4, q, p,
-                                      acc);
+      wgrad_compute<R, TPW, ROWSPLIT, TT>(a, ldsX, ldsG, regionRows, wave, g4, q,
+                                          p, acc);
     }
   }
 
@@ -276,26 +287,31 @@ inline int ilog2(int v) {
   return l;
 }
 
-template <int R, int TPW, bool ROWSPLIT, bool PIPE>
+template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT>
 int launch_wgrad1(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&wgrad_kernel<R, TPW, ROWSPLIT, PIPE>),
+        reinterpret_cast<const void*>(
+            &wgrad_kernel<R, TPW, ROWSPLIT, PIPE, TT>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<R, TPW, ROWSPLIT, PIPE>), grid, dim3(512),
-                     lds, s, a);
+  hipLaunchKernelGGL((wgrad_kernel<R, TPW, ROWSPLIT, PIPE, TT>), grid,
+                     dim3(512), lds, s, a);
   CG_LAUNCH_CHECK();
 }
 
 template <int R, int TPW, bool ROWSPLIT>
-int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, bool pipe,
+int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, bool pipe, int tt,
                  hipStream_t s) {
-  if (pipe) return launch_wgrad1<R, TPW, ROWSPLIT, true>(a, grid, 2 * lds, s);
-  return launch_wgrad1<R, TPW, ROWSPLIT, false>(a, grid, lds, s);
+  constexpr int T0 = ROWSPLIT ? 256 : 64;
+  if (!ROWSPLIT && tt == 128)  // only chosen with pipe
+    return launch_wgrad1<R, TPW, ROWSPLIT, true, ROWSPLIT ? 256 : 128>(
+        a, grid, 2 * lds, s);
+  if (pipe) return launch_wgrad1<R, TPW, ROWSPLIT, true, T0>(a, grid, 2 * lds, s);
+  return launch_wgrad1<R, TPW, ROWSPLIT, false, T0>(a, grid, lds, s);
 }
 
 }  // namespace
@@ -311,7 +327,11 @@ extern "C" int cg_wgrad(const cg_wgrad_desc* d, void* stream) {
   if (d->Cx % 8 || d->Cg % 8 || d->Cx_real > d->Cx || d->Cg_real > d->Cg)
     return CG_EINVAL;
   if (d->shifts && d->seg_size < 1) return CG_EINVAL;
-  const int TT = rowsplit ? 256 : 64;
+  // 128-row tiles (half the per-tile barrier / staging overhead) when one
+  // sample spans whole tiles, else 64
+  int TT = rowsplit ? 256 : 64;
+  if (!rowsplit && d->Lu % 128 == 0 && d->tile_rows != 64) TT = 128;
+  if (d->tile_rows == 128 && (rowsplit || d->Lu % 128)) return CG_EINVAL;
   int S;
   if (d->Lu >= TT) {
     if (d->Lu % TT) return CG_EINVAL;
@@ -351,8 +371,8 @@ extern "C" int cg_wgrad(const cg_wgrad_desc* d, void* stream) {
   if (nsplit < 1) nsplit = 1;
   dim3 grid(gx, gy, nsplit);
   hipStream_t s = (hipStream_t)stream;
-  if (rowsplit) return launch_wgrad<1, 1, true>(a, grid, lds, pipe, s);
-  if (d->taps <= 8) return launch_wgrad<2, 1, false>(a, grid, lds, pipe, s);
-  if (d->taps <= 16) return launch_wgrad<2, 2, false>(a, grid, lds, pipe, s);
-  return launch_wgrad<2, 3, false>(a, grid, lds, pipe, s);
+  if (rowsplit) return launch_wgrad<1, 1, true>(a, grid, lds, pipe, TT, s);
+  if (d->taps <= 8) return launch_wgrad<2, 1, false>(a, grid, lds, pipe, TT, s);
+  if (d->taps <= 16) return launch_wgrad<2, 2, false>(a, grid, lds, pipe, TT, s);
+  return launch_wgrad<2, 3, false>(a, grid, lds, pipe, TT, s);
 }

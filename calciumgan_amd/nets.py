@@ -194,7 +194,62 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
   if small == 0 and stride == 2 and CK <= 32 and Lu % 128 == 0:
     small = 2
   d.small_tile = small
+  _autotune_tile(d)
   return d
+
+
+# Row-tile choice by measurement: the best of {256, 128, 64}-row tiles depends
+# on how the launch quantises over 256 CUs and on LDS residency, so each
+# distinct launch geometry is timed once (3 runs per candidate, a few hundred
+# microseconds in total) when its descriptor is first built.  Every candidate
+# computes bit-identical results (same K order per output element).
+_TILE_CACHE = {}
+_AUTOTUNE = __import__('os').environ.get('CALCIUMGAN_AUTOTUNE', '1') != '0'
+_TILE_ROWS = {0: 256, 2: 128, 1: 64}
+
+
+def _autotune_tile(d):
+  if not _AUTOTUNE or not torch.cuda.is_available():
+    return
+  key = (d.stride, d.taps, d.nB, d.Lx, d.Cx, d.Lu, d.N, d.CK, d.nphase,
+         d.epilogue, d.out_f32)
+  best = _TILE_CACHE.get(key)
+  if best is None:
+    lib = _lib.load()
+    st = _stream()
+    cands = []
+    for small, tm in _TILE_ROWS.items():
+      ok = (d.Lu % tm == 0) if d.Lu >= tm else (tm % d.Lu == 0)
+      if ok and geo.lds_bytes(d.CK, d.stride, d.taps, d.Lu, tm) <= geo.LDS_BYTES:
+        cands.append(small)
+    times = {}
+    y_saved = d.y
+    scratch = None
+    if d.mask_src and d.mask_src == d.y:
+      # in-place launch (penalty tangent): tune on a scratch output so live
+      # activations are not rewritten
+      nbytes = d.nB * d.Ly * d.Cy * (4 if d.out_f32 else 2)
+      scratch = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+      d.y = scratch.data_ptr()
+    for small in cands:
+      d.small_tile = small
+      if lib.cg_swconv(ctypes.byref(d), st) != 0:
+        continue
+      s = torch.cuda.Event(enable_timing=True)
+      e = torch.cuda.Event(enable_timing=True)
+      s.record()
+      for _ in range(3):
+        lib.cg_swconv(ctypes.byref(d), st)
+      e.record()
+      e.synchronize()
+      times[small] = s.elapsed_time(e)
+    d.y = y_saved
+    del scratch
+    if not times:
+      return
+    best = min(times, key=times.get)
+    _TILE_CACHE[key] = best
+  d.small_tile = best
 
 
 def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,

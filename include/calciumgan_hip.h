@@ -130,6 +130,7 @@ typedef struct cg_wgrad_desc {
   int taps, stride, off;
   int Cx_real, Cg_real;
   int nsplit;        /* 0 = choose */
+  int tile_rows;     /* 0 = choose; 64 or 128 rows of (b,u) per staged tile */
 } cg_wgrad_desc;
 int cg_wgrad(const cg_wgrad_desc* d, void* stream);
 

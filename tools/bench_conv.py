@@ -81,11 +81,13 @@ def main():
     d = nets._wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, R,
                          0 if taps == 1 else -(taps - 2) // 2, Cx, Cg)
     d.nsplit = nsplit
+    d.tile_rows = a[7] if len(a) > 7 else 0
     st = nets._stream()
     t = timeit(lambda: _lib.call('cg_wgrad', ctypes.byref(d), st))
     fl = 2.0 * nB * Lu * Cg * taps * Cx
-    print('wgrad R%d taps%d nB%d Lu%d Cx%d Cg%d nsplit%d: %.1f us  %.1f TF/s' %
-          (R, taps, nB, Lu, Cx, Cg, nsplit, t * 1e6, fl / t / 1e12))
+    print('wgrad R%d taps%d nB%d Lu%d Cx%d Cg%d nsplit%d tile%d: %.1f us  %.1f TF/s'
+          % (R, taps, nB, Lu, Cx, Cg, nsplit, d.tile_rows, t * 1e6,
+             fl / t / 1e12))
 
 
 if __name__ == '__main__':

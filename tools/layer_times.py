@@ -26,6 +26,7 @@ def main():
   hp = bench.make_hparams(2048, 102, 64, 10)
   gen, dis = get_models(hp, None)
   gan = get_algorithm(hp, gen, dis, None)
+  gan._use_graph = False
   real = torch.rand(args.batch, 2048, 102, device=gan.device)
   gan.train(real)
   recs = []
