@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
       ('off_phase_step', c_i), ('yoff_phase_step', c_i),
       ('small_tile', c_i),
       ('stage_ksteps', c_i),
+      ('rowsumsq', c_vp),
   ]
 
 
@@ -73,19 +74,19 @@ SIGNATURES = {
     'cg_ln_lrelu_fwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_f,
                         c_f, c_vp],
     'cg_ln_lrelu_bwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                        c_ll, c_i, c_i, c_f, c_vp],
+                        c_vp, c_ll, c_i, c_i, c_f, c_vp],
     'cg_dense1_fwd': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     'cg_dense1_bwd': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f,
                       c_vp],
     'cg_dense1_wgrad': [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i,
                         c_vp],
     'cg_unshuffle_mask': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f,
-                          c_vp],
+                          c_vp, c_i, c_i, c_vp],
     'cg_interp_pack': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_vp],
     'cg_cast_pad': [c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],
     'cg_rownorm': [c_vp, c_vp, c_i, c_ll, c_vp],
-    'cg_gp_finalize': [c_vp, c_vp, c_vp, c_i, c_f, c_vp],
+    'cg_gp_finalize': [c_vp, c_vp, c_vp, c_i, c_f, c_i, c_vp],
     'cg_scale_rows': [c_vp, c_vp, c_vp, c_i, c_ll, c_vp],
     'cg_critic_loss': [c_vp, c_vp, c_f, c_vp, c_i, c_vp],
     'cg_neg_mean': [c_vp, c_vp, c_i, c_vp],

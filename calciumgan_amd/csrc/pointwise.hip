@@ -113,13 +113,15 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
     const uint16_t* __restrict__ y, const float* __restrict__ mean_i,
     const float* __restrict__ rstd_i, const float* __restrict__ gamma,
     uint16_t* __restrict__ dy, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, long long rows, int C, int Cp, float alpha,
-    int lpr, int log2lpr, int rows_per_slot) {
+    float* __restrict__ dbeta, float* __restrict__ dbias, long long rows, int C,
+    int Cp, float alpha, int lpr, int log2lpr, int rows_per_slot) {
   __shared__ float sg[512];
   __shared__ float sb[512];
+  __shared__ float sd[512];
   for (int c = threadIdx.x; c < 512; c += kThreads) {
     sg[c] = 0.f;
     sb[c] = 0.f;
+    sd[c] = 0.f;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -130,12 +132,13 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
       (long long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   const int c0 = sub * 8;
   const bool active = c0 < Cp;
-  float gam[8], accg[8], accb[8];
+  float gam[8], accg[8], accb[8], accd[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     gam[e] = (active && c0 + e < C) ? gamma[c0 + e] : 0.f;
     accg[e] = 0.f;
     accb[e] = 0.f;
+    accd[e] = 0.f;
   }
   const float invC = 1.f / C;
   const long long row0 = wave_id * (long long)rpw * rows_per_slot + slot;
@@ -176,8 +179,10 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
     if (rv && active) {
       float o[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
+      for (int e = 0; e < 8; ++e) {
         o[e] = (c0 + e < C) ? rstd * (dyh[e] - s1 - xh[e] * s2) : 0.f;
+        accd[e] += bf2f(f2bf(o[e]));  // bias gradient of the producing conv
+      }
       store8(dy + row * Cp + c0, o);
     }
   }
@@ -187,12 +192,14 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
       if (c0 + e < C) {
         atomicAdd(&sg[c0 + e], accg[e]);
         atomicAdd(&sb[c0 + e], accb[e]);
+        if (dbias) atomicAdd(&sd[c0 + e], accd[e]);
       }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += kThreads) {
     atomicAdd(dgamma + c, sg[c]);
     atomicAdd(dbeta + c, sb[c]);
+    if (dbias) atomicAdd(dbias + c, sd[c]);
   }
 }
 
@@ -274,48 +281,80 @@ __global__ __launch_bounds__(kThreads) void dense1_wgrad_kernel(
 // ---------------------------------------------------------------------------
 // phase unshuffle + LeakyReLU mask
 // ---------------------------------------------------------------------------
+// Thread -> one 8-channel group (tid % per_row), walking `rows_per_block`
+// rows of the block with step kThreads / per_row, so the optional bias
+// gradient (column sum of delta over the first bias_rows_b samples) accumulates
+// in registers and costs one LDS + one global atomic per channel per block.
 __global__ __launch_bounds__(kThreads) void unshuffle_mask_kernel(
     const uint16_t* __restrict__ e, const uint16_t* __restrict__ h,
     uint16_t* __restrict__ delta, const int* __restrict__ shifts, int w, int Cp,
-    int seg_size, float alpha, long long total8) {
-  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
-  if (idx >= total8) return;
+    int C, int seg_size, float alpha, long long rows, int rows_per_block,
+    float* __restrict__ dbias, int bias_samples) {
+  extern __shared__ float sacc[];  // [Cp]
   const int per_row = Cp / 8;
-  const long long rowg = idx / per_row;
-  const int c = (int)(idx - rowg * per_row) * 8;
-  const int b = (int)(rowg / w);
-  const int r = (int)(rowg - (long long)b * w);
-  const int s = shifts ? shifts[b / seg_size] : 0;
-  // all t with shuffle_src(t, s, w) == r
-  int t0, t1 = -1;
-  if (s > 0) {
-    t0 = r - s;                    // direct branch, valid if t0 >= 0
-    const int tr = 2 * (w - 1) - s - r;  // reflected branch, t in [w-s, w-1]
-    if (tr >= w - s && tr <= w - 1) t1 = tr;
-  } else {
-    const int a = -s;
-    t0 = r + a;                    // direct branch t >= a, valid if t0 < w
-    if (t0 >= w) t0 = -1;
-    const int tr = a - r;          // reflected branch t in [0, a)
-    if (tr >= 0 && tr < a) t1 = tr;
+  const int rlanes = kThreads / per_row;
+  if (dbias) {
+    for (int c = threadIdx.x; c < Cp; c += kThreads) sacc[c] = 0.f;
+    __syncthreads();
   }
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  float v[8];
-  const long long base = (long long)b * w;
-  if (t0 >= 0) {
-    load8(e + (base + t0) * Cp + c, v);
+  const int grp = threadIdx.x % per_row;
+  const int rl = threadIdx.x / per_row;
+  const int c = grp * 8;
+  float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < rlanes) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    for (int rr = rl; rr < rows_per_block; rr += rlanes) {
+      const long long rowg = r0 + rr;
+      if (rowg >= rows) break;
+      const int b = (int)(rowg / w);
+      const int r = (int)(rowg - (long long)b * w);
+      const int s = shifts ? shifts[b / seg_size] : 0;
+      // all t with shuffle_src(t, s, w) == r
+      int t0, t1 = -1;
+      if (s > 0) {
+        t0 = r - s;                          // direct branch, valid if t0 >= 0
+        const int tr = 2 * (w - 1) - s - r;  // reflected, t in [w-s, w-1]
+        if (tr >= w - s && tr <= w - 1) t1 = tr;
+      } else {
+        const int a = -s;
+        t0 = r + a;                          // direct branch t >= a
+        if (t0 >= w) t0 = -1;
+        const int tr = a - r;                // reflected branch t in [0, a)
+        if (tr >= 0 && tr < a) t1 = tr;
+      }
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      float v[8];
+      const long long base = (long long)b * w;
+      if (t0 >= 0) {
+        load8(e + (base + t0) * Cp + c, v);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+      }
+      if (t1 >= 0) {
+        load8(e + (base + t1) * Cp + c, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+      }
+      load8(h + rowg * Cp + c, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] *= (v[k] > 0.f ? 1.f : alpha);
+      store8(delta + rowg * Cp + c, acc);
+      if (dbias && b < bias_samples) {
+        // the gradient that flows on is the bf16-stored delta
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bsum[k] += bf2f(f2bf(acc[k]));
+      }
+    }
   }
-  if (t1 >= 0) {
-    load8(e + (base + t1) * Cp + c, v);
+  if (dbias) {
+    if (rl < rlanes) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+      for (int k = 0; k < 8; ++k) atomicAdd(&sacc[c + k], bsum[k]);
+    }
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < C; cc += kThreads)
+      atomicAdd(dbias + cc, sacc[cc]);
   }
-  load8(h + rowg * Cp + c, v);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] *= (v[k] > 0.f ? 1.f : alpha);
-  store8(delta + rowg * Cp + c, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -384,14 +423,18 @@ __global__ void sqrt_kernel(float* v, int n) {
   if (i < n) v[i] = sqrtf(v[i]);
 }
 
-__global__ void gp_finalize_kernel(const float* __restrict__ norm,
+__global__ void gp_finalize_kernel(float* __restrict__ norm,
                                    float* __restrict__ gp,
-                                   float* __restrict__ coef, int B,
-                                   float scale) {
+                                   float* __restrict__ coef, int B, float scale,
+                                   int squared) {
   __shared__ float part[4];
   float s = 0.f;
   for (int b = threadIdx.x; b < B; b += kThreads) {
-    const float nv = norm[b];
+    float nv = norm[b];
+    if (squared) {
+      nv = sqrtf(nv);
+      norm[b] = nv;
+    }
     const float d = nv - 1.f;
     s += d * d;
     coef[b] = scale * 2.f * d / (B * nv);
@@ -608,8 +651,8 @@ extern "C" int cg_ln_lrelu_fwd(const void* y_pre, const float* gamma,
 extern "C" int cg_ln_lrelu_bwd(const void* dh, const void* h, const void* y_pre,
                                const float* mean, const float* rstd,
                                const float* gamma, void* dy, float* dgamma,
-                               float* dbeta, long long rows, int C, int Cp,
-                               float alpha, void* stream) {
+                               float* dbeta, float* dbias, long long rows,
+                               int C, int Cp, float alpha, void* stream) {
   if (Cp % 8 || Cp > 512 || C > Cp || rows < 1) return CG_EINVAL;
   int lpr = 1, l2 = 0;
   while (lpr * 8 < Cp) { lpr <<= 1; ++l2; }
@@ -618,8 +661,8 @@ extern "C" int cg_ln_lrelu_bwd(const void* dh, const void* h, const void* y_pre,
   hipLaunchKernelGGL(ln_bwd_kernel,
                      dim3(grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31)),
                      dim3(kThreads), 0, S_(stream), U16(dh), U16(h), U16(y_pre),
-                     mean, rstd, gamma, U16W(dy), dgamma, dbeta, rows, C, Cp,
-                     alpha, lpr, l2, rows_per_slot);
+                     mean, rstd, gamma, U16W(dy), dgamma, dbeta, dbias, rows, C,
+                     Cp, alpha, lpr, l2, rows_per_slot);
   CG_LAUNCH_CHECK();
 }
 
@@ -663,13 +706,19 @@ extern "C" int cg_dense1_wgrad(const void* x, const float* coef,
 
 extern "C" int cg_unshuffle_mask(const void* e, const void* h, void* delta,
                                  const int* shifts, int nB, int w, int Cp,
-                                 int seg_size, float alpha, void* stream) {
-  if (Cp % 8 || nB < 1 || w < 1 || seg_size < 1) return CG_EINVAL;
-  const long long total8 = (long long)nB * w * Cp / 8;
+                                 int seg_size, float alpha, float* dbias, int C,
+                                 int bias_samples, void* stream) {
+  if (Cp % 8 || Cp / 8 > kThreads || nB < 1 || w < 1 || seg_size < 1 || C > Cp)
+    return CG_EINVAL;
+  const long long rows = (long long)nB * w;
+  int rows_per_block = 64;
+  while (rows_per_block < 1024 && rows / (rows_per_block * 2) >= 1024)
+    rows_per_block *= 2;
   hipLaunchKernelGGL(unshuffle_mask_kernel,
-                     dim3(grid1d(total8, kThreads, 1LL << 31)), dim3(kThreads),
-                     0, S_(stream), U16(e), U16(h), U16W(delta), shifts, w, Cp,
-                     seg_size, alpha, total8);
+                     dim3(grid1d(rows, rows_per_block, 1LL << 31)),
+                     dim3(kThreads), dbias ? Cp * sizeof(float) : 0, S_(stream),
+                     U16(e), U16(h), U16W(delta), shifts, w, Cp, C, seg_size,
+                     alpha, rows, rows_per_block, dbias, bias_samples);
   CG_LAUNCH_CHECK();
 }
 
@@ -710,10 +759,10 @@ extern "C" int cg_rownorm(const float* g, float* norm, int B, long long n,
   CG_LAUNCH_CHECK();
 }
 
-extern "C" int cg_gp_finalize(const float* norm, float* gp, float* coef, int B,
-                              float scale, void* stream) {
+extern "C" int cg_gp_finalize(float* norm, float* gp, float* coef, int B,
+                              float scale, int squared, void* stream) {
   hipLaunchKernelGGL(gp_finalize_kernel, dim3(1), dim3(kThreads), 0, S_(stream),
-                     norm, gp, coef, B, scale);
+                     norm, gp, coef, B, scale, squared);
   CG_LAUNCH_CHECK();
 }
 

@@ -35,6 +35,7 @@ struct ConvArgs {
   const float* bias;
   const uint16_t* mask;
   const int* shifts;
+  float* rowsumsq;
   int nB, Lx, Cx, seg_size;
   int taps, off, Lu, M;
   int N, Ly, Cy, y_stride, y_off;
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
   float* scr = reinterpret_cast<float*>(smem) + wave * (16 * kScrPitch);
   const int erow = lane >> 2;
   const int ecol = (lane & 3) * 16;
+  float ssq = 0.f;  // sum of squares of this lane's outputs (rowsumsq)
   float bv[2][8];  // this lane's 16 output channels' bias (0 when absent/pad)
 #pragma unroll
   for (int half = 0; half < 2; ++half)
@@ -333,6 +335,10 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
             for (int e = 0; e < 8; ++e)
               if (e >= nval) v[e] = 0.f;
           }
+          if (a.rowsumsq) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
+          }
           if (a.out_f32) {
             float* dst = reinterpret_cast<float*>(a.y) + rowoff + n;
             *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
@@ -349,6 +355,12 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (a.rowsumsq) {
+    // the whole tile belongs to one sample (nseg == 1, checked on the host):
+    // one f32 atomic per wave
+    ssq = wave_sum(ssq);
+    if (lane == 0 && m0 < a.M) atomicAdd(a.rowsumsq + m0 / a.Lu, ssq);
   }
 }
 
@@ -553,6 +565,7 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   a.bias = d->bias;
   a.mask = reinterpret_cast<const uint16_t*>(d->mask_src);
   a.shifts = d->shifts;
+  a.rowsumsq = d->rowsumsq;
   a.nB = d->nB; a.Lx = d->Lx; a.Cx = d->Cx; a.seg_size = d->seg_size;
   a.taps = d->taps; a.off = d->off; a.Lu = d->Lu;
   a.M = d->nB * d->Lu;
@@ -567,6 +580,7 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   a.pitchA = d->CK + 8 * ((6 - (a.c8 & 3)) & 3);  // slots == 2 (mod 4)
   a.S = S; a.log2S = ilog2(S); a.nseg = TM / S;
   a.WR = S + d->taps / R - 1;
+  if (d->rowsumsq && a.nseg != 1) return CG_EINVAL;  // one sample per tile
   a.ldsA_elems = R * a.nseg * a.WR * a.pitchA;
   a.epilogue = d->epilogue; a.out_f32 = d->out_f32; a.alpha = d->alpha;
   a.w_phase_stride = d->w_phase_stride;

@@ -171,9 +171,11 @@ def _ck_for(Cx, stride, taps, Lu):
 def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
                y_stride=1, y_off=0, bias=None, mask_src=None, shifts=None,
                seg_size=1, epilogue=_lib.EPI_NONE, out_f32=False, nphase=1,
-               w_phase_stride=0, off_phase_step=0, yoff_phase_step=0):
+               w_phase_stride=0, off_phase_step=0, yoff_phase_step=0,
+               rowsumsq=None):
   d = ConvDesc()
-  d._keep = (x, w, y, bias, mask_src, shifts)  # pointers below borrow these
+  d._keep = (x, w, y, bias, mask_src, shifts, rowsumsq)  # borrowed pointers
+  d.rowsumsq = rowsumsq.data_ptr() if rowsumsq is not None else None
   d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
   d.bias = bias.data_ptr() if bias is not None else None
   d.mask_src = mask_src.data_ptr() if mask_src is not None else None
@@ -220,6 +222,8 @@ def _autotune_tile(d):
     cands = []
     for small, tm in _TILE_ROWS.items():
       ok = (d.Lu % tm == 0) if d.Lu >= tm else (tm % d.Lu == 0)
+      if d.rowsumsq and d.Lu < tm:
+        ok = False
       if ok and geo.lds_bytes(d.CK, d.stride, d.taps, d.Lu, tm) <= geo.LDS_BYTES:
         cands.append(small)
     times = {}
@@ -451,13 +455,18 @@ class _DisPlan(object):
       self.nG = nG
       self.gin = torch.zeros(
           nG, lay.lin, lay.cinp, dtype=torch.float32, device=dev)
+      # penalty norm fused into this launch's epilogue when a 256-row tile
+      # never spans two samples; else the standalone cg_rownorm is used
+      self.sumsq = None
+      if lay.lin // 2 >= 256 and (lay.lin // 2) % 256 == 0:
+        self.sumsq = torch.zeros(nG, dtype=torch.float32, device=dev)
       self.input_grad = _conv_desc(
           ws.delta[1][input_grad_from:], op.buf, self.gin, nG, lay.lout,
           lay.coutp, k // 2, 1, net.dgrad_offs[0], lay.lin // 2, lay.cin,
           lay.lin, lay.cinp, op.CK, y_stride=2, y_off=0, out_f32=True, nphase=2,
           w_phase_stride=op.elems,
           off_phase_step=net.dgrad_offs[1] - net.dgrad_offs[0],
-          yoff_phase_step=1)
+          yoff_phase_step=1, rowsumsq=self.sumsq)
 
   def build_jvp(self, seg_index):
     """Tangent-forward chain (gradient-penalty second backward) over segment
@@ -488,9 +497,12 @@ class _DisPlan(object):
     _lib.call('cg_dense1_fwd', _p(ws.act[-1]), _p(net.dense_w), _p(net.dense_b),
               _p(ws.d_out), self.nB, last.lout, last.cout, last.coutp, st)
 
-  def backward_chain(self):
+  def backward_chain(self, bias_samples=0):
     """delta[5] = coef * w_d * lrelu'(h5); then down to delta[1]; optional
-    layer-1 input gradient into self.gin (f32)."""
+    layer-1 input gradient into self.gin (f32).  bias_samples > 0 also
+    accumulates the conv bias gradients of layers 1-4 (column sums of delta
+    over the first bias_samples samples) into params.grad, which the caller
+    must have zeroed."""
     st = _stream()
     net, ws = self.ws.net, self.ws
     last = net.layers[-1]
@@ -500,10 +512,14 @@ class _DisPlan(object):
     for i, d in self.dgrad:
       _run_conv(d, st)
       lay = net.layers[i - 1]
+      dbias = net.params.grad_views[2 * (i - 1) + 1] if bias_samples else None
       _lib.call('cg_unshuffle_mask', _p(ws.e[i]), _p(ws.act[i]),
                 _p(ws.delta[i]), _p(self.shifts[i - 1]), self.nB, lay.lout,
-                lay.coutp, self.seg_size, LEAKY_ALPHA, st)
+                lay.coutp, self.seg_size, LEAKY_ALPHA, _p(dbias), lay.cout,
+                bias_samples, st)
     if self.input_grad is not None:
+      if self.sumsq is not None:
+        self.sumsq.zero_()
       _run_conv(self.input_grad, st)
 
   def jvp_forward(self):
@@ -519,7 +535,8 @@ class _DisPlan(object):
     for i, d in enumerate(self.wgrad):
       _run_wgrad(d, st)
       lay = net.layers[i]
-      if bias_rows > 0:
+      # layers 1-4: fused into backward_chain's unshuffle kernel
+      if bias_rows > 0 and i == len(self.wgrad) - 1:
         _lib.call('cg_colsum', _p(ws.delta[i + 1]),
                   _p(net.params.grad_views[2 * i + 1]),
                   bias_rows * lay.lout, lay.cout, lay.coutp, st)
@@ -722,14 +739,14 @@ class _GenWorkspace(object):
         _lib.call('cg_ln_lrelu_bwd', _p(self.dh[i + 1]), _p(self.h[i + 1]),
                   _p(self.ypre[i + 1]), _p(self.mean[i + 1]),
                   _p(self.rstd[i + 1]), _p(V[ic + 2]), _p(self.dy[i + 1]),
-                  _p(G[ic + 2]), _p(G[ic + 3]), n, lay.cout, lay.coutp,
-                  LEAKY_ALPHA, st)
+                  _p(G[ic + 2]), _p(G[ic + 3]), _p(G[ic + 1]), n, lay.cout,
+                  lay.coutp, LEAKY_ALPHA, st)
       else:
         _lib.call('cg_lrelu_bwd', _p(self.dh[i + 1]), _p(self.h[i + 1]),
                   _p(self.dy[i + 1]), n * lay.coutp, LEAKY_ALPHA, st)
+        _lib.call('cg_colsum', _p(self.dy[i + 1]), _p(G[ic + 1]), n, lay.cout,
+                  lay.coutp, st)
       _run_wgrad(self.b_wgrad[i], st)
-      _lib.call('cg_colsum', _p(self.dy[i + 1]), _p(G[ic + 1]), n, lay.cout,
-                lay.coutp, st)
       _run_conv(self.b_dgrad[i], st)
     nflat = net.w0 * net.nd
     _lib.call('cg_lrelu_bwd', _p(self.dh[0]), _p(self.h[0]), _p(self.dy[0]),

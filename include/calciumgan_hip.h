@@ -78,6 +78,8 @@ typedef struct cg_conv_desc {
   int off_phase_step, yoff_phase_step;
   int small_tile;       /* 0: 256-row tiles, 1: 64-row tiles */
   int stage_ksteps;     /* 0: choose; 2 or 4: MFMA K-steps per weight stage */
+  float* rowsumsq;      /* optional f32 [nB]: += sum over (row, n) of y^2 per
+                           sample (penalty norm, wgan_gp.py:49); needs Lu >= tile */
 } cg_conv_desc;
 
 int cg_swconv(const cg_conv_desc* d, void* stream);
@@ -144,12 +146,14 @@ int cg_ln_lrelu_fwd(const void* y_pre /*bf16 [rows][Cp]*/, const float* gamma,
                     float* mean /*[rows] or NULL*/, float* rstd /*[rows] or NULL*/,
                     long long rows, int C, int Cp, float eps, float alpha,
                     void* stream);
-/* dy = d(loss)/d(y_pre); dgamma/dbeta accumulated with f32 atomics. */
+/* dy = d(loss)/d(y_pre); dgamma/dbeta (and, when dbias != NULL, the bias
+ * gradient of the producing conv = column sums of dy) accumulated with f32
+ * atomics. */
 int cg_ln_lrelu_bwd(const void* dh /*bf16*/, const void* h /*bf16*/,
                     const void* y_pre /*bf16*/, const float* mean,
                     const float* rstd, const float* gamma, void* dy /*bf16*/,
-                    float* dgamma, float* dbeta, long long rows, int C, int Cp,
-                    float alpha, void* stream);
+                    float* dgamma, float* dbeta, float* dbias, long long rows,
+                    int C, int Cp, float alpha, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Discriminator head: Flatten + Dense(1) (calciumgan.py:188-190).
@@ -175,10 +179,12 @@ int cg_dense1_wgrad(const void* x /*bf16 [nB][Lt][Cp]*/, const float* coef,
  * Backward of LeakyReLU + PhaseShuffle between discriminator layers:
  *   delta[b][r][c] = lrelu'(h[b][r][c]) * sum_{t: src(t)=r} e[b][t][c]
  * where src is the reflect gather of PhaseShuffle (calciumgan.py:117-138).
- * ------------------------------------------------------------------------- */
+ * When dbias != NULL also accumulates the conv bias gradient
+ *   dbias[c] += sum_{b < bias_samples, r} delta[b][r][c]   (c < C). */
 int cg_unshuffle_mask(const void* e /*bf16 [nB][w][Cp]*/, const void* h,
                       void* delta, const int* shifts, int nB, int w, int Cp,
-                      int seg_size, float alpha, void* stream);
+                      int seg_size, float alpha, float* dbias, int C,
+                      int bias_samples, void* stream);
 
 /* ---------------------------------------------------------------------------
  * WGAN-GP elementwise / reduction pieces (gan/algorithms/wgan_gp.py).
@@ -195,9 +201,11 @@ int cg_cast_pad(const float* src, void* dst, long long rows, int C, int Cs,
                 int Cp, void* stream);
 /* norm[b] = ||g[b]||_2 over n elements (wgan_gp.py:49), g f32 [B][n] */
 int cg_rownorm(const float* g, float* norm, int B, long long n, void* stream);
-/* gp = mean((norm-1)^2) (wgan_gp.py:50); coef[b] = scale*2*(norm-1)/(B*norm) */
-int cg_gp_finalize(const float* norm, float* gp, float* coef, int B,
-                   float scale, void* stream);
+/* gp = mean((norm-1)^2) (wgan_gp.py:50); coef[b] = scale*2*(norm-1)/(B*norm).
+ * squared != 0: `norm` holds sums of squares on entry and is replaced by their
+ * square roots. */
+int cg_gp_finalize(float* norm, float* gp, float* coef, int B, float scale,
+                   int squared, void* stream);
 /* a0 bf16 [B][n] = coef[b] * g[b] */
 int cg_scale_rows(const float* g, const float* coef, void* a0, int B,
                   long long n, void* stream);

@@ -314,8 +314,10 @@ def test_layernorm_lrelu_fwd_bwd(rows, C):
   dy = torch.zeros(1, rows, cp, dtype=BF16, device=H.DEV)
   dg = torch.zeros(C, device=H.DEV)
   db = torch.zeros(C, device=H.DEV)
+  dbias = torch.zeros(C, device=H.DEV)
   _lib.call('cg_ln_lrelu_bwd', H.p(dhd), H.p(h), H.p(yd), H.p(mean), H.p(rstd),
-            H.p(gd), H.p(dy), H.p(dg), H.p(db), rows, C, cp, ALPHA, H.stream())
+            H.p(gd), H.p(dy), H.p(dg), H.p(db), H.p(dbias), rows, C, cp, ALPHA,
+            H.stream())
   H.sync()
   np.testing.assert_allclose(
       dy.float().cpu()[0, :, :C].numpy(), yq.grad[0].numpy(), rtol=2e-2,
@@ -324,6 +326,10 @@ def test_layernorm_lrelu_fwd_bwd(rows, C):
                              atol=1e-3)
   np.testing.assert_allclose(db.cpu().numpy(), b_.grad.numpy(), rtol=1e-3,
                              atol=1e-3)
+  # fused bias gradient of the producing conv = column sums of the stored dy
+  np.testing.assert_allclose(dbias.cpu().numpy(),
+                             dy.float().cpu()[0, :, :C].sum(0).numpy(),
+                             rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize('w,m', [(16, 3), (64, 10), (8, 1)])
@@ -344,12 +350,17 @@ def test_unshuffle_mask_is_adjoint_of_shuffle(w, m):
   hd = H.to_pitch(O.leaky_relu(hx.detach()), cp)
   delta = torch.zeros(nB, w, cp, dtype=BF16, device=H.DEV)
   sh = torch.tensor(shifts, device=H.DEV)
+  dbias = torch.zeros(C, device=H.DEV)
   _lib.call('cg_unshuffle_mask', H.p(ed), H.p(hd), H.p(delta), H.p(sh), nB, w,
-            cp, seg, ALPHA, H.stream())
+            cp, seg, ALPHA, H.p(dbias), C, 4, H.stream())
   H.sync()
   np.testing.assert_allclose(
       delta.float().cpu()[:, :, :C].numpy(),
       hx.grad.to(BF16).float().numpy(), rtol=0, atol=0)
+  # fused bias gradient: column sums of delta over the first 4 samples
+  np.testing.assert_allclose(
+      dbias.cpu().numpy(),
+      delta.float().cpu()[:4, :, :C].sum((0, 1)).numpy(), rtol=1e-5, atol=1e-4)
 
 
 def test_discriminator_head_kernels():
@@ -420,7 +431,8 @@ def test_wgan_gp_elementwise_kernels():
   gp = torch.zeros(1, device=H.DEV)
   coef = torch.zeros(B, device=H.DEV)
   _lib.call('cg_rownorm', H.p(gd), H.p(norm), B, L * cp, H.stream())
-  _lib.call('cg_gp_finalize', H.p(norm), H.p(gp), H.p(coef), B, 10.0, H.stream())
+  _lib.call('cg_gp_finalize', H.p(norm), H.p(gp), H.p(coef), B, 10.0, 0,
+            H.stream())
   a0 = torch.zeros(B, L * cp, dtype=BF16, device=H.DEV)
   _lib.call('cg_scale_rows', H.p(gd), H.p(coef), H.p(a0), B, L * cp, H.stream())
   H.sync()

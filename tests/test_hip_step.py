@@ -120,7 +120,7 @@ def test_critic_step_matches_oracle(name):
                                rtol=tol, atol=tol * 0.1)
     np.testing.assert_allclose(d_out[B:2 * B], res['fake_out'][:, 0].numpy(),
                                rtol=tol, atol=tol * 0.1)
-    np.testing.assert_allclose(st['norm'].cpu().numpy(), res['norm'].numpy(),
+    np.testing.assert_allclose(st['norm_out'].cpu().numpy(), res['norm'].numpy(),
                                rtol=tol)
     np.testing.assert_allclose(float(gp), float(res['gp']), rtol=tol)
     np.testing.assert_allclose(float(loss), float(res['loss']), rtol=tol)
@@ -297,7 +297,7 @@ def test_hip_step_against_committed_golden():
   loss, gp = gan._train_discriminator(d['real'], r, slot=0)
   torch.cuda.synchronize()
   st = gan._get_state(4)
-  np.testing.assert_allclose(st['norm'].cpu().numpy(), d['norm'], rtol=3e-2)
+  np.testing.assert_allclose(st['norm_out'].cpu().numpy(), d['norm'], rtol=3e-2)
   np.testing.assert_allclose(float(gp), d['gp'], rtol=3e-2)
   np.testing.assert_allclose(float(loss), d['dis_loss'], rtol=3e-2)
   fake = st['gws'].fake[:, :, :6].cpu().numpy()
