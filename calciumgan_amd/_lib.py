@@ -58,6 +58,8 @@ class WgradDesc(C.Structure):
       ('Cx_real', c_i), ('Cg_real', c_i),
       ('nsplit', c_i),
       ('tile_rows', c_i),
+      ('dbias', c_vp),
+      ('bias_rows', c_ll),
   ]
 
 
@@ -81,7 +83,7 @@ SIGNATURES = {
     'cg_dense1_wgrad': [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i,
                         c_vp],
     'cg_unshuffle_mask': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f,
-                          c_vp, c_i, c_i, c_vp],
+                          c_vp],
     'cg_interp_pack': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_vp],
     'cg_cast_pad': [c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],

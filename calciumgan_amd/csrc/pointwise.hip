@@ -281,80 +281,48 @@ __global__ __launch_bounds__(kThreads) void dense1_wgrad_kernel(
 // ---------------------------------------------------------------------------
 // phase unshuffle + LeakyReLU mask
 // ---------------------------------------------------------------------------
-// Thread -> one 8-channel group (tid % per_row), walking `rows_per_block`
-// rows of the block with step kThreads / per_row, so the optional bias
-// gradient (column sum of delta over the first bias_rows_b samples) accumulates
-// in registers and costs one LDS + one global atomic per channel per block.
 __global__ __launch_bounds__(kThreads) void unshuffle_mask_kernel(
     const uint16_t* __restrict__ e, const uint16_t* __restrict__ h,
     uint16_t* __restrict__ delta, const int* __restrict__ shifts, int w, int Cp,
-    int C, int seg_size, float alpha, long long rows, int rows_per_block,
-    float* __restrict__ dbias, int bias_samples) {
-  extern __shared__ float sacc[];  // [Cp]
+    int seg_size, float alpha, long long total8) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
   const int per_row = Cp / 8;
-  const int rlanes = kThreads / per_row;
-  if (dbias) {
-    for (int c = threadIdx.x; c < Cp; c += kThreads) sacc[c] = 0.f;
-    __syncthreads();
+  const long long rowg = idx / per_row;
+  const int c = (int)(idx - rowg * per_row) * 8;
+  const int b = (int)(rowg / w);
+  const int r = (int)(rowg - (long long)b * w);
+  const int s = shifts ? shifts[b / seg_size] : 0;
+  // all t with shuffle_src(t, s, w) == r
+  int t0, t1 = -1;
+  if (s > 0) {
+    t0 = r - s;                    // direct branch, valid if t0 >= 0
+    const int tr = 2 * (w - 1) - s - r;  // reflected branch, t in [w-s, w-1]
+    if (tr >= w - s && tr <= w - 1) t1 = tr;
+  } else {
+    const int a = -s;
+    t0 = r + a;                    // direct branch t >= a, valid if t0 < w
+    if (t0 >= w) t0 = -1;
+    const int tr = a - r;          // reflected branch t in [0, a)
+    if (tr >= 0 && tr < a) t1 = tr;
   }
-  const int grp = threadIdx.x % per_row;
-  const int rl = threadIdx.x / per_row;
-  const int c = grp * 8;
-  float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (rl < rlanes) {
-    const long long r0 = (long long)blockIdx.x * rows_per_block;
-    for (int rr = rl; rr < rows_per_block; rr += rlanes) {
-      const long long rowg = r0 + rr;
-      if (rowg >= rows) break;
-      const int b = (int)(rowg / w);
-      const int r = (int)(rowg - (long long)b * w);
-      const int s = shifts ? shifts[b / seg_size] : 0;
-      // all t with shuffle_src(t, s, w) == r
-      int t0, t1 = -1;
-      if (s > 0) {
-        t0 = r - s;                          // direct branch, valid if t0 >= 0
-        const int tr = 2 * (w - 1) - s - r;  // reflected, t in [w-s, w-1]
-        if (tr >= w - s && tr <= w - 1) t1 = tr;
-      } else {
-        const int a = -s;
-        t0 = r + a;                          // direct branch t >= a
-        if (t0 >= w) t0 = -1;
-        const int tr = a - r;                // reflected branch t in [0, a)
-        if (tr >= 0 && tr < a) t1 = tr;
-      }
-      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      float v[8];
-      const long long base = (long long)b * w;
-      if (t0 >= 0) {
-        load8(e + (base + t0) * Cp + c, v);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float v[8];
+  const long long base = (long long)b * w;
+  if (t0 >= 0) {
+    load8(e + (base + t0) * Cp + c, v);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += v[k];
-      }
-      if (t1 >= 0) {
-        load8(e + (base + t1) * Cp + c, v);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += v[k];
-      }
-      load8(h + rowg * Cp + c, v);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] *= (v[k] > 0.f ? 1.f : alpha);
-      store8(delta + rowg * Cp + c, acc);
-      if (dbias && b < bias_samples) {
-        // the gradient that flows on is the bf16-stored delta
-#pragma unroll
-        for (int k = 0; k < 8; ++k) bsum[k] += bf2f(f2bf(acc[k]));
-      }
-    }
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
   }
-  if (dbias) {
-    if (rl < rlanes) {
+  if (t1 >= 0) {
+    load8(e + (base + t1) * Cp + c, v);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) atomicAdd(&sacc[c + k], bsum[k]);
-    }
-    __syncthreads();
-    for (int cc = threadIdx.x; cc < C; cc += kThreads)
-      atomicAdd(dbias + cc, sacc[cc]);
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
   }
+  load8(h + rowg * Cp + c, v);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] *= (v[k] > 0.f ? 1.f : alpha);
+  store8(delta + rowg * Cp + c, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -706,19 +674,13 @@ extern "C" int cg_dense1_wgrad(const void* x, const float* coef,
 
 extern "C" int cg_unshuffle_mask(const void* e, const void* h, void* delta,
                                  const int* shifts, int nB, int w, int Cp,
-                                 int seg_size, float alpha, float* dbias, int C,
-                                 int bias_samples, void* stream) {
-  if (Cp % 8 || Cp / 8 > kThreads || nB < 1 || w < 1 || seg_size < 1 || C > Cp)
-    return CG_EINVAL;
-  const long long rows = (long long)nB * w;
-  int rows_per_block = 64;
-  while (rows_per_block < 1024 && rows / (rows_per_block * 2) >= 1024)
-    rows_per_block *= 2;
+                                 int seg_size, float alpha, void* stream) {
+  if (Cp % 8 || nB < 1 || w < 1 || seg_size < 1) return CG_EINVAL;
+  const long long total8 = (long long)nB * w * Cp / 8;
   hipLaunchKernelGGL(unshuffle_mask_kernel,
-                     dim3(grid1d(rows, rows_per_block, 1LL << 31)),
-                     dim3(kThreads), dbias ? Cp * sizeof(float) : 0, S_(stream),
-                     U16(e), U16(h), U16W(delta), shifts, w, Cp, C, seg_size,
-                     alpha, rows, rows_per_block, dbias, bias_samples);
+                     dim3(grid1d(total8, kThreads, 1LL << 31)), dim3(kThreads),
+                     0, S_(stream), U16(e), U16(h), U16W(delta), shifts, w, Cp,
+                     seg_size, alpha, total8);
   CG_LAUNCH_CHECK();
 }
 

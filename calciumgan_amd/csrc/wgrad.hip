@@ -31,6 +31,8 @@ struct WgradArgs {
   int Cx_real, Cg_real;
   int S, log2S, nseg, WR;
   int ntiles;
+  float* dbias;
+  long long bias_rows;
 };
 
 constexpr int kPitchX = 48;  // 32 ch + 16 pad  (96 B = 32*3)
@@ -94,6 +96,28 @@ __device__ __forceinline__ void wgrad_compute(const WgradArgs& a,
   }
 }
 
+// Bias gradient for free: workgroups of the first cx chunk add the column sums
+// of the g tile they have just staged (rows < bias_rows only).  Thread ->
+// channel pair (tid & 31), row group tid >> 5 (16 groups).
+template <int TT>
+__device__ __forceinline__ void colsum_tile(const uint16_t* ldsG, int m0,
+                                            long long bias_rows, int tid,
+                                            float& s0, float& s1) {
+  const int cp = (tid & 31) * 2;
+  const int rg = tid >> 5;
+  constexpr int RPG = TT / 16;
+#pragma unroll
+  for (int k = 0; k < RPG; ++k) {
+    const int row = rg * RPG + k;
+    if (m0 + row < bias_rows) {
+      const uint32_t w =
+          *reinterpret_cast<const uint32_t*>(ldsG + row * kPitchG + cp);
+      s0 += __uint_as_float(w << 16);
+      s1 += __uint_as_float(w & 0xffff0000u);
+    }
+  }
+}
+
 // R: source stride (1|2).  TPW: taps per wave.  ROWSPLIT: taps == 1, the waves
 // split the staged rows (TT = 256) instead of the taps (TT = 64).  PIPE: one
 // sample per tile (nseg == 1): tiles are double-buffered in LDS and the next
@@ -128,6 +152,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
 
   const int totalX = R * regionRows * 4;
   const int totalG = TT * 8;
+  const bool do_bias = a.dbias != nullptr && blockIdx.x == 0;
+  float bs0 = 0.f, bs1 = 0.f;
 
   if (PIPE) {
     // per-thread piece coordinates (fixed across tiles)
@@ -209,6 +235,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
       const bool more = tile + stride < a.ntiles;
       if (more) load_tile(tile + stride);
       const uint16_t* base = lds + cur * (bufX + bufG);
+      if (do_bias && (long long)tile * TT < a.bias_rows)
+        colsum_tile<TT>(base + bufX, tile * TT, a.bias_rows, tid, bs0, bs1);
       wgrad_compute<R, TPW, ROWSPLIT, TT>(a, base, base + bufX, regionRows, wave,
                                           g4, q, p, acc);
       if (more) {
@@ -257,9 +285,24 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
         *reinterpret_cast<uint4*>(ldsG + row * kPitchG + q8 * 8) = v;
       }
       __syncthreads();
+      if (do_bias && (long long)m0 < a.bias_rows)
+        colsum_tile<TT>(ldsG, m0, a.bias_rows, tid, bs0, bs1);
       wgrad_compute<R, TPW, ROWSPLIT, TT>(a, ldsX, ldsG, regionRows, wave, g4, q,
                                           p, acc);
     }
+  }
+  if (do_bias) {
+    // 16 row groups -> one value per channel through LDS, then one global
+    // atomic per channel per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    if (tid < 64) red[tid] = 0.f;
+    __syncthreads();
+    const int cp = (tid & 31) * 2;
+    atomicAdd(&red[cp], bs0);
+    atomicAdd(&red[cp + 1], bs1);
+    __syncthreads();
+    if (tid < 64 && cg0 + tid < a.Cg_real) atomicAdd(a.dbias + cg0 + tid, red[tid]);
   }
 
 #pragma unroll
@@ -353,6 +396,8 @@ extern "C" int cg_wgrad(const cg_wgrad_desc* d, void* stream) {
   const int R = d->stride;
   a.WR = S + d->taps / R - 1;
   a.ntiles = (a.M + TT - 1) / TT;
+  a.dbias = d->dbias;
+  a.bias_rows = d->bias_rows;
   const size_t lds =
       ((size_t)R * a.nseg * a.WR * kPitchX + (size_t)TT * kPitchG) * 2;
   if (lds > 160 * 1024) return CG_EINVAL;

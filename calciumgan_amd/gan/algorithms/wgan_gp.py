@@ -79,7 +79,7 @@ class WGAN_GP(GAN):
     return -fake_output.mean()
 
   def _critic_forward(self, st, real, z, alpha, shifts, slot,
-                      real_cached=False, bias_grads=False):
+                      real_cached=False):
     """Steps 1-5 of the critic schedule; leaves g in st['critic'].gin."""
     net_d = self.discriminator.net
     B = real.shape[0]
@@ -92,11 +92,7 @@ class WGAN_GP(GAN):
               nets._p(st['dws'].act[0]), B, lay.lin, lay.cin, lay.cin, lay.cinp,
               lay.cinp, 0 if real_cached else 1, s)
     plan.forward()
-    # conv bias gradients of layers 1-4 ride along in the chain's unshuffle
-    # kernels (real + fake segments only: the penalty has no bias gradient)
-    if bias_grads:
-      self.discriminator.net.params.grad.zero_()
-    plan.backward_chain(bias_samples=2 * B if bias_grads else 0)
+    plan.backward_chain()
     n = lay.lin * lay.cinp
     if plan.sumsq is not None:  # ||g||^2 came out of the dgrad epilogue
       norm = plan.sumsq
@@ -137,8 +133,7 @@ class WGAN_GP(GAN):
           torch.as_tensor(r['shifts_fake'], dtype=torch.int32),
           torch.as_tensor(r['shifts_inter'], dtype=torch.int32)
       ], dim=1)
-    self._critic_forward(st, real, z, alpha, shifts, slot, real_cached,
-                         bias_grads=True)
+    self._critic_forward(st, real, z, alpha, shifts, slot, real_cached)
     plan = st['critic']
     s = nets._stream()
     n = lay.lin * lay.cinp
@@ -146,7 +141,9 @@ class WGAN_GP(GAN):
     _lib.call('cg_scale_rows', nets._p(plan.gin), nets._p(st['coef_gp']),
               nets._p(st['dws'].act[0][2 * B:]), B, n, s)
     plan.jvp_forward()
-    plan.weight_grads(bias_rows=2 * B)  # grad buffer zeroed in _critic_forward
+    net_d.params.grad.zero_()
+    # bias gradients: real + fake segments only (the penalty has none)
+    plan.weight_grads(bias_rows=2 * B)
 
   def _critic_apply(self, lr_t_dev=None):
     self.dis_optimizer.update(self.discriminator, self._sync.grad_scale,

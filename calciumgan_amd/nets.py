@@ -257,9 +257,11 @@ def _autotune_tile(d):
 
 
 def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,
-                Cg_real, shifts=None, seg_size=1):
+                Cg_real, shifts=None, seg_size=1, dbias=None, bias_rows=0):
   d = WgradDesc()
-  d._keep = (x, g, dw, shifts)  # pointers below borrow these
+  d._keep = (x, g, dw, shifts, dbias)  # pointers below borrow these
+  d.dbias = dbias.data_ptr() if dbias is not None else None
+  d.bias_rows = bias_rows
   d.x, d.g, d.dw = x.data_ptr(), g.data_ptr(), dw.data_ptr()
   d.shifts = shifts.data_ptr() if shifts is not None else None
   d.nB, d.Lx, d.Cx, d.seg_size = nB, Lx, Cx, seg_size
@@ -432,7 +434,8 @@ class _DisPlan(object):
       self.wgrad.append(
           _wgrad_desc(ws.act[i], ws.delta[i + 1], net.params.grad_views[2 * i],
                       nB, lay.lin, lay.cinp, lay.lout, lay.coutp, k, 2, -pl,
-                      lay.cin, lay.cout, shifts=sh, seg_size=seg_size))
+                      lay.cin, lay.cout, shifts=sh, seg_size=seg_size,
+                      dbias=net.params.grad_views[2 * i + 1]))
     # input-gradient chain: layer i (1-based l = i+1) maps delta[l] -> e[l-1]
     for i in range(len(net.layers) - 1, 0, -1):
       lay = net.layers[i]
@@ -497,12 +500,9 @@ class _DisPlan(object):
     _lib.call('cg_dense1_fwd', _p(ws.act[-1]), _p(net.dense_w), _p(net.dense_b),
               _p(ws.d_out), self.nB, last.lout, last.cout, last.coutp, st)
 
-  def backward_chain(self, bias_samples=0):
+  def backward_chain(self):
     """delta[5] = coef * w_d * lrelu'(h5); then down to delta[1]; optional
-    layer-1 input gradient into self.gin (f32).  bias_samples > 0 also
-    accumulates the conv bias gradients of layers 1-4 (column sums of delta
-    over the first bias_samples samples) into params.grad, which the caller
-    must have zeroed."""
+    layer-1 input gradient into self.gin (f32)."""
     st = _stream()
     net, ws = self.ws.net, self.ws
     last = net.layers[-1]
@@ -512,11 +512,9 @@ class _DisPlan(object):
     for i, d in self.dgrad:
       _run_conv(d, st)
       lay = net.layers[i - 1]
-      dbias = net.params.grad_views[2 * (i - 1) + 1] if bias_samples else None
       _lib.call('cg_unshuffle_mask', _p(ws.e[i]), _p(ws.act[i]),
                 _p(ws.delta[i]), _p(self.shifts[i - 1]), self.nB, lay.lout,
-                lay.coutp, self.seg_size, LEAKY_ALPHA, _p(dbias), lay.cout,
-                bias_samples, st)
+                lay.coutp, self.seg_size, LEAKY_ALPHA, st)
     if self.input_grad is not None:
       if self.sumsq is not None:
         self.sumsq.zero_()
@@ -528,18 +526,14 @@ class _DisPlan(object):
       _run_conv(d, st)
 
   def weight_grads(self, bias_rows):
-    """Accumulate dW (all nB samples), db (first bias_rows samples) and the
-    dense head gradients into params.grad (caller zeroed it)."""
+    """Accumulate dW (all nB samples), db (first bias_rows samples; taken
+    inside the wgrad kernel from the delta tiles it stages) and the dense head
+    gradients into params.grad (caller zeroed it)."""
     st = _stream()
     net, ws = self.ws.net, self.ws
     for i, d in enumerate(self.wgrad):
+      d.bias_rows = bias_rows * net.layers[i].lout
       _run_wgrad(d, st)
-      lay = net.layers[i]
-      # layers 1-4: fused into backward_chain's unshuffle kernel
-      if bias_rows > 0 and i == len(self.wgrad) - 1:
-        _lib.call('cg_colsum', _p(ws.delta[i + 1]),
-                  _p(net.params.grad_views[2 * i + 1]),
-                  bias_rows * lay.lout, lay.cout, lay.coutp, st)
     last = net.layers[-1]
     _lib.call('cg_dense1_wgrad', _p(ws.act[-1]), _p(self.coef),
               _p(self.bias_coef), _p(net.params.grad_views[-2]),

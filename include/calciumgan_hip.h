@@ -133,6 +133,10 @@ typedef struct cg_wgrad_desc {
   int Cx_real, Cg_real;
   int nsplit;        /* 0 = choose */
   int tile_rows;     /* 0 = choose; 64 or 128 rows of (b,u) per staged tile */
+  float* dbias;      /* optional f32 [Cg_real]: += sum of g over its first
+                        bias_rows (b,u) rows -- the conv bias gradient, taken
+                        from the g tiles already staged in LDS */
+  long long bias_rows;
 } cg_wgrad_desc;
 int cg_wgrad(const cg_wgrad_desc* d, void* stream);
 
@@ -179,12 +183,10 @@ int cg_dense1_wgrad(const void* x /*bf16 [nB][Lt][Cp]*/, const float* coef,
  * Backward of LeakyReLU + PhaseShuffle between discriminator layers:
  *   delta[b][r][c] = lrelu'(h[b][r][c]) * sum_{t: src(t)=r} e[b][t][c]
  * where src is the reflect gather of PhaseShuffle (calciumgan.py:117-138).
- * When dbias != NULL also accumulates the conv bias gradient
- *   dbias[c] += sum_{b < bias_samples, r} delta[b][r][c]   (c < C). */
+ * ------------------------------------------------------------------------- */
 int cg_unshuffle_mask(const void* e /*bf16 [nB][w][Cp]*/, const void* h,
                       void* delta, const int* shifts, int nB, int w, int Cp,
-                      int seg_size, float alpha, float* dbias, int C,
-                      int bias_samples, void* stream);
+                      int seg_size, float alpha, void* stream);
 
 /* ---------------------------------------------------------------------------
  * WGAN-GP elementwise / reduction pieces (gan/algorithms/wgan_gp.py).
