@@ -1,11 +1,13 @@
-import csv, glob, sys
+"""Condense a rocprofv3 --stats kernel_stats.csv into per-step milliseconds."""
+import csv, glob, re, sys
 d, steps = sys.argv[1], float(sys.argv[2])
-f = glob.glob(d + "/*/*kernel_stats.csv")[0]
+f = glob.glob(d + "/*/*kernel_stats.csv")[0] if not d.endswith('.csv') else d
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("total kernel ms/step", tot / 1e6 / steps)
+print("launch set: %s  (divided by %g recorded train() steps incl. warm-up/timing passes)" % (f.split('/')[-1], steps))
+print("total kernel ms/step %.2f" % (tot / 1e6 / steps))
 for r in rows[:34]:
     n = r["Name"]
-    n = n.split("::")[-1] if "::" in n else n
-    n = n.replace("((anonymous namespace)", "(")[:52]
-    print("%-52s %5s %8.1f us  %6.2f ms/step %5.1f%%" % (n, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6 / steps, float(r["Percentage"])))
+    m = re.search(r"(\w+_kernel(<[^>]*>)?)", n)
+    n = m.group(1) if m else n[:52]
+    print("%-40s %6s calls %8.1f us avg %6.2f ms/step %5.1f%%" % (n[:40], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6 / steps, float(r["Percentage"])))
