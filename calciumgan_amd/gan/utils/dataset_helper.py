@@ -1,0 +1,116 @@
+"""Input pipeline for the hot path (gan/utils/dataset_helper.py:113-206).
+
+The reference reads TFRecords of raw-float32 `signal` / `spike` features;
+TensorFlow is not available here, so the dataset directory holds the same
+segments as ``train.npy`` / ``validation.npy`` dicts next to an ``info.pkl``
+with the reference's keys (dataset/generate_tfrecords.py:229-248).  Batches
+are float32 (B, L, C) in [0, 1]; the last batch of an epoch may be short
+(no drop_remainder, dataset_helper.py:173)."""
+import os
+import pickle
+from math import ceil
+
+import numpy as np
+
+from . import h5_helper
+
+
+class ArrayDataset(object):
+  """Iterable of (signal, spike) batches; reshuffled every epoch when asked
+  (tf.data shuffle(buffer) + batch, dataset_helper.py:170-174)."""
+
+  def __init__(self, signals, spikes, batch_size, shuffle, seed=1234):
+    self.signals, self.spikes = signals, spikes
+    self.batch_size, self.shuffle = batch_size, shuffle
+    self._rng = np.random.RandomState(seed)
+
+  def __len__(self):
+    return ceil(len(self.signals) / self.batch_size)
+
+  def __iter__(self):
+    idx = np.arange(len(self.signals))
+    if self.shuffle:
+      self._rng.shuffle(idx)
+    for i in range(0, len(idx), self.batch_size):
+      j = np.sort(idx[i:i + self.batch_size])
+      yield self.signals[j], self.spikes[j]
+
+
+def get_dataset_info(hparams):
+  """dataset_helper.py:113-144."""
+  with open(os.path.join(hparams.input_dir, 'info.pkl'), 'rb') as file:
+    info = pickle.load(file)
+  hparams.train_size = info['train_size']
+  hparams.validation_size = info['validation_size']
+  hparams.signal_shape = tuple(info['signal_shape'])
+  hparams.spike_shape = tuple(info['spike_shape'])
+  hparams.sequence_length = info['sequence_length']
+  hparams.num_neurons = info['num_neurons']
+  hparams.num_channels = info['num_channels']
+  hparams.normalize = info['normalize']
+  hparams.fft = info['fft']
+  hparams.conv2d = info['conv2d']
+  if hparams.normalize:
+    hparams.signals_min = float(info['signals_min'])
+    hparams.signals_max = float(info['signals_max'])
+  if hparams.save_generated:
+    hparams.generated_dir = os.path.join(hparams.output_dir, 'generated')
+    os.makedirs(hparams.generated_dir, exist_ok=True)
+    hparams.validation_cache = os.path.join(hparams.generated_dir,
+                                            'validation.h5')
+
+
+def cache_validation_set(hparams, validation):
+  """dataset_helper.py:12-30: validation signals (denormalised) + spikes in
+  generated/validation.h5, written once."""
+  if os.path.exists(hparams.validation_cache):
+    return
+  sig = validation['signals']
+  if hparams.normalize:
+    sig = sig * (hparams.signals_max - hparams.signals_min) + hparams.signals_min
+  h5_helper.write(hparams.validation_cache, {
+      'signals': sig.astype(np.float32),
+      'spikes': validation['spikes'].astype(np.int8)
+  })
+
+
+def get_dataset(hparams, summary=None):
+  """dataset_helper.py:185-206."""
+  hparams.noise_shape = (hparams.noise_dim,)
+  if not os.path.exists(hparams.input_dir):
+    print('input directory {} cannot be found'.format(hparams.input_dir))
+    exit()
+  get_dataset_info(hparams)
+  with open(os.path.join(hparams.input_dir, 'train.npy'), 'rb') as f:
+    train = pickle.load(f)
+  with open(os.path.join(hparams.input_dir, 'validation.npy'), 'rb') as f:
+    validation = pickle.load(f)
+  if hparams.save_generated:
+    cache_validation_set(hparams, validation)
+  train_ds = ArrayDataset(train['signals'], train['spikes'], hparams.batch_size,
+                          shuffle=True)
+  validation_ds = ArrayDataset(validation['signals'], validation['spikes'],
+                               hparams.batch_size, shuffle=False)
+  hparams.train_steps = ceil(hparams.train_size / hparams.batch_size)
+  hparams.validation_steps = ceil(hparams.validation_size / hparams.batch_size)
+  return train_ds, validation_ds
+
+
+def write_dataset(output_dir, signals, spikes, info, validation_size):
+  """Counterpart of dataset/generate_tfrecords.py:186-252: shuffle, split
+  off `validation_size` segments, write train/validation arrays + info.pkl."""
+  os.makedirs(output_dir, exist_ok=True)
+  rng = np.random.RandomState(1234)  # generate_tfrecords.py:14
+  idx = rng.permutation(len(signals))
+  train_size = len(signals) - validation_size
+  parts = {'train': idx[:train_size], 'validation': idx[train_size:]}
+  for name, ii in parts.items():
+    with open(os.path.join(output_dir, name + '.npy'), 'wb') as f:
+      pickle.dump({'signals': signals[ii], 'spikes': spikes[ii]}, f, protocol=4)
+  full = dict(info)
+  full.update(train_size=train_size, validation_size=validation_size,
+              num_train_shards=1, num_validation_shards=1,
+              buffer_size=train_size)
+  with open(os.path.join(output_dir, 'info.pkl'), 'wb') as f:
+    pickle.dump(full, f)
+  return full

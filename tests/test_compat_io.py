@@ -1,0 +1,149 @@
+"""CPU tests of the compatibility layer around the hot path (SURVEY 8(f)
+rows 3-4, Appendix C): CLI flag surface, hparams.json, checkpoint pickle
+layout + resume, generated-sample store, scalar tags, dataset directory."""
+import json
+import os
+import pickle
+from types import SimpleNamespace
+
+import numpy as np
+
+import main as cli
+from calciumgan_amd.data import dg
+from calciumgan_amd.gan.utils import dataset_helper, h5_helper, utils
+from calciumgan_amd.gan.utils.summary_helper import Summary
+
+
+class _FakeModel(object):
+
+  def __init__(self, weights):
+    self._w = [w.copy() for w in weights]
+
+  def get_weights(self):
+    return [w.copy() for w in self._w]
+
+  def set_weights(self, w):
+    self._w = [np.asarray(a).copy() for a in w]
+
+
+def _fake_gan():
+  rng = np.random.RandomState(0)
+  g = _FakeModel([rng.randn(3, 4).astype(np.float32), rng.randn(4)])
+  d = _FakeModel([rng.randn(24, 2, 5).astype(np.float32)])
+  return SimpleNamespace(generator=g, discriminator=d,
+                         gen_optimizer=SimpleNamespace(iterations=7),
+                         dis_optimizer=SimpleNamespace(iterations=35))
+
+
+def test_cli_flags_match_reference_defaults():
+  p = cli.build_parser().parse_args([])
+  ref = dict(input_dir='dataset/tfrecords', output_dir='runs', batch_size=64,
+             num_units=32, kernel_size=24, strides=2, m=2, n=2, epochs=20,
+             dropout=0.2, learning_rate=0.0001, noise_dim=32,
+             gradient_penalty=10.0, model='wavegan', activation='leakyrelu',
+             batch_norm=False, layer_norm=False, algorithm='wgan-gp',
+             n_critic=5, clear_output_dir=False, save_generated='',
+             plot_weights=False, skip_checkpoints=False, mixed_precision=False,
+             profile=False, dpi=120, verbose=1)  # main.py:228-262
+  assert vars(p) == ref
+  p = cli.build_parser().parse_args(
+      '--batch_size 128 --model calciumgan --algorithm wgan-gp --noise_dim 32 '
+      '--num_units 64 --kernel_size 24 --strides 2 --m 10 --layer_norm '
+      '--mixed_precision --save_generated all'.split())  # README.md:92
+  assert p.num_units == 64 and p.layer_norm and p.m == 10
+
+
+def test_checkpoint_layout_and_resume(tmp_path):
+  hp = SimpleNamespace(output_dir=str(tmp_path), verbose=0,
+                       ckpt_dir=str(tmp_path / 'checkpoints'))
+  gan = _fake_gan()
+  utils.save_models(hp, gan, 3)
+  utils.save_models(hp, gan, 10)
+  path = tmp_path / 'checkpoints' / 'epoch-010.pkl'
+  ck = pickle.load(open(path, 'rb'))
+  assert sorted(ck) == ['dis_steps', 'dis_weights', 'epoch', 'gen_steps',
+                        'gen_weights']  # utils.py:121-128
+  assert ck['epoch'] == 10 and ck['gen_steps'] == 7 and ck['dis_steps'] == 35
+  assert ck['dis_weights'][0].shape == (24, 2, 5)
+  other = _fake_gan()
+  other.generator.set_weights([w * 0 for w in other.generator.get_weights()])
+  other.gen_optimizer.iterations = 0
+  hp2 = SimpleNamespace(output_dir=str(tmp_path), verbose=0)
+  utils.load_models(hp2, other)
+  assert hp2.start_epoch == 11  # lexicographically last epoch-*, +1
+  np.testing.assert_array_equal(other.generator.get_weights()[0],
+                                gan.generator.get_weights()[0])
+  assert other.gen_optimizer.iterations == 7
+  empty = SimpleNamespace(output_dir=str(tmp_path / 'none'), verbose=0)
+  utils.load_models(empty, other)
+  assert empty.start_epoch == 0
+
+
+def test_hparams_json_roundtrip(tmp_path):
+  hp = SimpleNamespace(output_dir=str(tmp_path), signal_shape=(2048, 102),
+                       signals_min=np.float32(-1.5), global_step=3,
+                       focus_neurons=[1, 2])
+  utils.save_hparams(hp)  # must not crash outside a git checkout
+  d = json.load(open(tmp_path / 'hparams.json'))
+  assert d['signal_shape'] == [2048, 102] and 'git_hash' in d
+  hp2 = SimpleNamespace(output_dir=str(tmp_path))
+  utils.load_hparams(hp2)
+  assert hp2.global_step == 3 and hp2.output_dir == str(tmp_path)
+
+
+def test_generated_samples_store(tmp_path):
+  gen_dir = tmp_path / 'generated'
+  os.makedirs(gen_dir)
+  hp = SimpleNamespace(generated_dir=str(gen_dir), normalize=True,
+                       signals_min=-1.0, signals_max=3.0, global_step=12)
+  a = np.full((2, 8, 3), 0.5, np.float32)
+  utils.save_fake_signals(hp, 0, a)
+  utils.save_fake_signals(hp, 0, a * 0)  # second validation batch appends
+  fn = str(gen_dir / 'epoch000_signals.h5')
+  assert h5_helper.contains(fn, 'signals')
+  assert h5_helper.get_dataset_length(fn, 'signals') == 4
+  out = h5_helper.get(fn, 'signals')
+  assert out.shape == (4, 8, 3) and out.dtype == np.float32
+  np.testing.assert_allclose(out[0], 1.0)  # denormalised: .5*4-1
+  np.testing.assert_allclose(out[3], -1.0)
+  assert h5_helper.get(fn, 'signals', neuron=1).shape == (4, 8)
+  assert h5_helper.get(fn, 'signals', trial=2).shape == (8, 3)
+  info = pickle.load(open(gen_dir / 'info.pkl', 'rb'))
+  assert info == {0: {'global_step': 12, 'filename': fn}}  # utils.py:104-113
+  h5_helper.overwrite(fn, 'signals', out[:1])
+  assert h5_helper.get_dataset_length(fn, 'signals') == 1
+
+
+def test_summary_tags(tmp_path):
+  hp = SimpleNamespace(output_dir=str(tmp_path))
+  s = Summary(hp)
+  s.log(1.0, 2.0, 3.0, elapse=4.0, step=5, training=True)
+  s.log(1.0, 2.0, None, metrics={'signals_metrics/min': 0.1}, step=5,
+        training=False)
+  tr = [json.loads(l) for l in open(tmp_path / 'scalars.jsonl')]
+  va = [json.loads(l) for l in open(tmp_path / 'validation' / 'scalars.jsonl')]
+  assert [r['tag'] for r in tr] == ['loss/generator', 'loss/discriminator',
+                                    'loss/gradient_penalty', 'elapse']
+  assert [r['tag'] for r in va] == ['loss/generator', 'loss/discriminator',
+                                    'signals_metrics/min']
+  assert all(r['step'] == 5 for r in tr + va)
+
+
+def test_dataset_directory_roundtrip(tmp_path):
+  d = dg.make_dataset(num_neurons=8, sequence_length=64, num_segments=20)
+  info = {k: v for k, v in d['info'].items() if k != 'rates_hz'}
+  dataset_helper.write_dataset(str(tmp_path / 'ds'), d['signals'], d['spikes'],
+                               info, validation_size=6)
+  hp = SimpleNamespace(input_dir=str(tmp_path / 'ds'),
+                       output_dir=str(tmp_path / 'run'), batch_size=4,
+                       noise_dim=32, save_generated='all')
+  train_ds, val_ds = dataset_helper.get_dataset(hp)
+  assert hp.signal_shape == (64, 8) and hp.train_size == 14
+  assert hp.validation_size == 6 and hp.train_steps == 4
+  assert hp.noise_shape == (32,) and hp.normalize and hp.num_channels == 8
+  batches = list(train_ds)
+  assert len(batches) == 4 and batches[-1][0].shape == (2, 64, 8)  # short tail
+  assert batches[0][0].dtype == np.float32
+  assert sum(len(b[0]) for b in val_ds) == 6
+  # validation cache for the spike-metric scripts (dataset_helper.py:12-30)
+  assert h5_helper.get(hp.validation_cache, 'spikes').dtype == np.int8
