@@ -55,5 +55,24 @@ def build(force=False, verbose=True):
   return LIB
 
 
+HOST_LIB = os.path.join(CSRC, 'libcalciumgan_host.so')
+HOST_SOURCES = ['oasis_ar1.c']
+
+
+def build_host(force=False, verbose=True):
+  """gcc build of the host-side C helpers (OASIS AR(1) deconvolution for the
+  post-hoc spike statistics; not part of the GPU hot path)."""
+  srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+  if (not force and os.path.exists(HOST_LIB) and
+      all(os.path.getmtime(s) <= os.path.getmtime(HOST_LIB) for s in srcs)):
+    return HOST_LIB
+  cmd = ['gcc', '-O2', '-shared', '-fPIC', '-o', HOST_LIB] + srcs + ['-lm']
+  if verbose:
+    print(' '.join(cmd), flush=True)
+  subprocess.check_call(cmd)
+  return HOST_LIB
+
+
 if __name__ == '__main__':
   build(force='--force' in sys.argv)
+  build_host(force='--force' in sys.argv)

@@ -1,0 +1,100 @@
+"""CPU tests of the spike-statistics chain: OASIS AR(1)
+deconvolution (C) against its python restatement and known answers, firing
+rate / binned covariance definitions, and the DG metrics report.  Upstream
+OASIS / Elephant are un-pinned and absent: PARITY UNPINNED."""
+import os
+import pickle
+from types import SimpleNamespace
+
+import numpy as np
+
+import compute_dg_metrics as cdm
+from calciumgan_amd.data import dg
+from calciumgan_amd.gan.utils import h5_helper, spike_helper, spike_metrics
+
+
+def test_oasis_c_matches_python_restatement():
+  rng = np.random.RandomState(0)
+  for seed in range(4):
+    s = (rng.rand(400) < 0.05).astype(np.float64)
+    c = np.zeros(400)
+    for t in range(400):
+      c[t] = s[t] + (0.95 * c[t - 1] if t > 0 else 0.0)
+    y = c + 0.3 * rng.randn(400)
+    for s_min in (0.0, 0.55):
+      c1, s1 = spike_helper.oasis_ar1(y, 0.95, s_min=s_min)
+      c2, s2 = spike_helper.oasis_ar1_python(y, 0.95, s_min=s_min)
+      np.testing.assert_allclose(c1, c2, rtol=1e-12, atol=1e-12)
+      np.testing.assert_allclose(s1, s2, rtol=1e-12, atol=1e-12)
+
+
+def test_oasis_recovers_noise_free_spikes():
+  T, g = 300, 0.95
+  s = np.zeros(T)
+  s[[20, 21, 90, 200, 260]] = 1.0
+  c = np.zeros(T)
+  for t in range(T):
+    c[t] = s[t] + (g * c[t - 1] if t > 0 else 0.0)
+  c_hat, s_hat = spike_helper.oasis_ar1(c, g, s_min=0.55)
+  np.testing.assert_allclose(c_hat, c, atol=1e-9)
+  np.testing.assert_allclose(s_hat, s, atol=1e-9)
+  np.testing.assert_array_equal(spike_helper.oasis_function(c), s)
+  # sub-threshold events are suppressed by s_min
+  small = c + 0.0
+  small[150:] += 0.3 * g**np.arange(150)
+  _, s2 = spike_helper.oasis_ar1(small, g, s_min=0.55)
+  assert s2[150] < 0.5
+
+
+def test_deconvolve_signals_on_dg_calcium():
+  """Noisy DG calcium (sn = .3): the recovered trains carry the firing rates."""
+  rng = np.random.RandomState(1)
+  gamma = np.array([-1.0, -1.5, -2.0])
+  spikes = dg.sample_spikes(gamma, 0.0, 6000, rng)
+  sig = dg.spikes_to_signals(spikes, rng)
+  rec = spike_helper.deconvolve_signals(sig)
+  assert rec.shape == spikes.shape and rec.dtype == np.float32
+  fr_true = spike_metrics.mean_firing_rate(spikes)
+  fr_rec = spike_metrics.mean_firing_rate(rec)
+  np.testing.assert_allclose(fr_rec, fr_true, rtol=0.25)
+
+
+def test_firing_rate_and_covariance_definitions():
+  sp = np.zeros((2, 48), np.float32)
+  sp[0, [0, 5, 13, 30]] = 1
+  sp[1, [1, 14, 15, 40, 41, 42]] = 1
+  np.testing.assert_allclose(spike_metrics.mean_firing_rate(sp), [2.0, 3.0])
+  counts = spike_metrics.bin_counts(sp)  # 12 frames per 500 ms bin
+  np.testing.assert_array_equal(counts, [[2, 1, 1, 0], [1, 2, 0, 3]])
+  np.testing.assert_allclose(spike_metrics.covariance(sp), np.cov(counts))
+  cross = spike_metrics.covariance(sp[:1], sp[1:])
+  assert cross.shape == (1, 1)
+  np.testing.assert_allclose(cross[0, 0], np.cov(counts)[1, 0])
+
+
+def test_dg_metrics_report(tmp_path):
+  d = dg.make_dataset(num_neurons=6, sequence_length=480, num_segments=8)
+  gen_dir = tmp_path / 'generated'
+  os.makedirs(gen_dir)
+  val = str(gen_dir / 'validation.h5')
+  sig = d['signals'] * (d['info']['signals_max'] - d['info']['signals_min']
+                        ) + d['info']['signals_min']
+  h5_helper.write(val, {'signals': sig.astype(np.float32),
+                        'spikes': d['spikes'].astype(np.int8)})
+  fake = str(gen_dir / 'epoch000_signals.h5')
+  h5_helper.write(fake, {'signals': sig.astype(np.float32)})
+  with open(gen_dir / 'info.pkl', 'wb') as f:
+    pickle.dump({0: {'global_step': 1, 'filename': fake}}, f)
+  import json
+  json.dump(dict(generated_dir=str(gen_dir), validation_cache=val,
+                 num_neurons=6), open(tmp_path / 'hparams.json', 'w'))
+  hp = SimpleNamespace(output_dir=str(tmp_path), num_trials=5)
+  r = cdm.main(hp)
+  # "generated" = the validation calcium itself: the only error is the
+  # deconvolution's, so rates agree closely
+  assert r['firing_rate']['mae'] < 0.5
+  assert r['covariance']['mae'] < 0.2
+  # identical inputs -> exactly zero error
+  fr, cov = cdm.get_data_statistics(hp, val)
+  z = cdm.report(fr, fr, cov, cov)
+  assert z['firing_rate']['rmse'] == 0 and z['covariance']['mse'] == 0
