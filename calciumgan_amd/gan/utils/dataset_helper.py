@@ -23,6 +23,17 @@ class ArrayDataset(object):
     self.signals, self.spikes = signals, spikes
     self.batch_size, self.shuffle = batch_size, shuffle
     self._rng = np.random.RandomState(seed)
+    self._dev_signals = None
+
+  def to_device(self, device):
+    """Keep the whole signal set resident in HBM (8192 x 2048 x 102 f32 is
+    6.8 GB of 288 GB): batches are then gathered on the device and the train
+    loop never waits for a host copy.  Spikes stay on the host (unused by
+    training, main.py:39)."""
+    import torch
+    self._dev_signals = torch.from_numpy(np.ascontiguousarray(
+        self.signals)).to(device)
+    return self
 
   def __len__(self):
     return ceil(len(self.signals) / self.batch_size)
@@ -33,7 +44,12 @@ class ArrayDataset(object):
       self._rng.shuffle(idx)
     for i in range(0, len(idx), self.batch_size):
       j = np.sort(idx[i:i + self.batch_size])
-      yield self.signals[j], self.spikes[j]
+      if self._dev_signals is not None:
+        import torch
+        jj = torch.from_numpy(j).to(self._dev_signals.device)
+        yield self._dev_signals.index_select(0, jj), self.spikes[j]
+      else:
+        yield self.signals[j], self.spikes[j]
 
 
 def get_dataset_info(hparams):

@@ -147,6 +147,9 @@ def main(hparams, return_metrics=False):
     utils.save_hparams(hparams)
   gan = get_algorithm(hparams, generator, discriminator, summary)
   utils.load_models(hparams, gan)
+  # dataset resident in HBM: no per-step host-to-device copy
+  train_ds.to_device(gan.device)
+  validation_ds.to_device(gan.device)
 
   start = time()
   train_and_validate(hparams, train_ds, validation_ds, gan, summary)
