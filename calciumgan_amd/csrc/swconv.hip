@@ -48,6 +48,7 @@ struct ConvArgs {
   int log2c8;  // log2(c8) when c8 is a power of two, else -1
   long long w_phase_stride;
   int off_phase_step, yoff_phase_step;
+  int gm, gn, gp;  // logical grid: row tiles, 64-col tiles, phases
 };
 
 // LDS row pitches are 2*odd 16-byte slots: with the MFMA operand map (lane ->
@@ -81,12 +82,23 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
   const int wave = tid >> 6;
   const int r16 = lane & 15;
   const int g = lane >> 4;
-  const int phase = blockIdx.z;
+  // XCD-aware mapping: the gn*gp workgroups that share one row tile's source
+  // window get linear ids congruent mod 8 (same XCD / L2) and adjacent in
+  // dispatch order; speed only, results do not depend on placement.
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7;
+  const int jq = lin >> 3;
+  const int gnp = a.gn * a.gp;
+  const int np_i = jq % gnp;
+  const int bm = (jq / gnp) * 8 + xcd;
+  if (bm >= a.gm) return;
+  const int bn = np_i % a.gn;
+  const int phase = np_i / a.gn;
   const uint16_t* __restrict__ wp = a.w + (long long)phase * a.w_phase_stride;
   const int off = a.off + phase * a.off_phase_step;
   const int y_off = a.y_off + phase * a.yoff_phase_step;
-  const int m0 = blockIdx.x * TM;
-  const int n0 = blockIdx.y * 64;
+  const int m0 = bm * TM;
+  const int n0 = bn * 64;
   const int regionRows = a.nseg * a.WR;
 
   int rowbase[MT];
@@ -600,7 +612,10 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   if (d->stage_ksteps == 2 || d->stage_ksteps == 4) ks = d->stage_ksteps;
   const size_t lds = ldsA_bytes + ldsB_bytes(ks);
   if (lds > 160 * 1024) return CG_EINVAL;
-  dim3 grid((a.M + TM - 1) / TM, (d->N + 63) / 64, d->nphase);
+  a.gm = (a.M + TM - 1) / TM;
+  a.gn = (d->N + 63) / 64;
+  a.gp = d->nphase;
+  dim3 grid((unsigned)(((a.gm + 7) / 8) * 8 * a.gn * a.gp));
   hipStream_t s = (hipStream_t)stream;
   const int mt = TM / 64;
 #define CG_DISPATCH(RR, MM, KK) \

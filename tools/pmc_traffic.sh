@@ -1,0 +1,34 @@
+# HBM traffic of the MFMA kernels from rocprofv3 PMC counters (separate passes
+# for FETCH_SIZE and WRITE_SIZE: they do not fit one pass on gfx950).
+export TMPDIR=/tmp
+export CALCIUMGAN_GRAPH=0
+export CALCIUMGAN_AUTOTUNE=0
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/traffic_$c -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_kernel_timing > gpurun_out/traffic_$c.log 2>&1
+done
+python3 - <<'PY'
+import csv, glob, collections, json
+res = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    for f in glob.glob('gpurun_out/traffic_%s/*/*counter_collection.csv' % c):
+        for r in csv.DictReader(open(f)):
+            n = r['Kernel_Name']
+            fam = 'swconv' if 'swconv_kernel' in n else ('wgrad' if 'wgrad_kernel' in n else None)
+            if fam is None or r['Counter_Name'] != c:
+                continue
+            a = res[fam][c]
+            a[0] += 1
+            a[1] += float(r['Counter_Value'])
+out = {}
+for fam, d in res.items():
+    n = d['FETCH_SIZE'][0]
+    fetch_kb = d['FETCH_SIZE'][1] / n
+    write_kb = d['WRITE_SIZE'][1] / d['WRITE_SIZE'][0]
+    # MI355X_MICROARCH.md "HBM": FETCH_SIZE reports exactly half the bytes of a
+    # wide (16 B/lane) coalesced streaming read on gfx950 -> doubled; WRITE_SIZE
+    # is exact for 16-B-per-lane stores and float atomics.  Units: KiB.
+    out[fam] = dict(launches=n, fetch_kib_raw=fetch_kb, write_kib=write_kb,
+                    hbm_bytes_per_launch=(2 * fetch_kb + write_kb) * 1024)
+print(json.dumps(out, indent=1))
+json.dump(out, open('gpurun_out/pmc_traffic.json', 'w'), indent=1)
+PY
