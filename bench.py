@@ -61,6 +61,47 @@ def algorithmic_flops(hp):
   return dict(total=total, swconv=swconv, wgrad=wgrad, f_g=f_g, f_d=f_d)
 
 
+def algorithmic_bytes_swconv(hp, B):
+  """Algorithmic HBM bytes of all cg_swconv launches of one train(): every
+  launch reads its bf16 source tensor and its packed bf16 weights once and
+  writes its output once (bf16, or f32 for the penalty gradient / generator
+  output).  Returns (bytes per step, launches per step)."""
+  from calciumgan_amd import geometry as geo
+  k, n = hp.kernel_size, hp.n_critic
+  g_l, d_l = geo.generator_layers(hp), geo.discriminator_layers(hp)
+  w0, nd, L, C = g_l[0].lin, hp.noise_dim, hp.signal_shape[0], hp.num_channels
+  cp = geo.pitch(C)
+
+  def conv(nb, lay, out_bytes=2):  # D conv fwd / tangent (stride 2)
+    return nb * (lay.lin * lay.cinp * 2 + lay.lout * lay.coutp * out_bytes) + \
+        k * lay.cinp * lay.cout * 2
+
+  def dgrad(nb, lay, out_bytes=2):  # D input gradient (two phases)
+    return nb * (lay.lout * lay.coutp * 2 + lay.lin * lay.cinp * out_bytes) + \
+        k * lay.coutp * lay.cin * 2
+
+  def convT(nb, lay):  # G conv-transpose fwd (two phases)
+    return nb * (lay.lin * lay.cinp * 2 + lay.lout * lay.coutp * 2) + \
+        k * lay.cinp * lay.cout * 2
+
+  def convT_dgrad(nb, lay):
+    return nb * (lay.lout * lay.coutp * 2 + lay.lin * lay.cinp * 2) + \
+        k * lay.coutp * lay.cin * 2
+
+  g_fwd = B * (nd * 2 + w0 * nd * 2) + nd * w0 * nd * 2
+  g_fwd += sum(convT(B, l) for l in g_l)
+  g_fwd += B * L * (cp * 2 + cp * 4) + cp * C * 2
+  g_bwd = B * L * (cp * 2 + cp * 2) + cp * C * 2
+  g_bwd += sum(convT_dgrad(B, l) for l in g_l)
+  d_fwd = lambda nb: sum(conv(nb, l) for l in d_l)
+  critic = g_fwd + d_fwd(3 * B) + sum(dgrad(3 * B, l) for l in d_l[1:])
+  critic += dgrad(B, d_l[0], 4) + d_fwd(B)  # x^ input gradient (f32) + tangent
+  gen = g_fwd + d_fwd(B) + sum(dgrad(B, l) for l in d_l[1:]) + \
+      dgrad(B, d_l[0], 4) + g_bwd
+  launches = n * (7 + 5 + 4 + 1 + 5) + (7 + 5 + 4 + 1 + 6)
+  return n * critic + gen, launches
+
+
 def cpu_baseline(hp, batch, steps):
   """The oracle (CPU restatement, NOT TensorFlow) timed on this box's host
   cores on a bounded sample of the same workload."""
@@ -193,6 +234,16 @@ def main():
           '{} steps run right after the timed region ({:.2f} ms/step '
           'eager vs {:.2f} ms/step timed)'.format(
               args.steps, dt_prof / args.steps * 1e3, dt / args.steps * 1e3))
+      ab, alaunch = algorithmic_bytes_swconv(hp, B)
+      roofline['algorithmic_hbm_bytes_per_launch'] = ab / alaunch
+      pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+      if os.path.exists(pmc):
+        # HBM bytes per launch from rocprofv3 PMC passes of this same command
+        # (tools/pmc_traffic.sh: FETCH_SIZE x2 per the gfx950 correction +
+        # WRITE_SIZE, separate passes); committed measurement, not live
+        t = json.load(open(pmc)).get('swconv', {})
+        roofline['traffic'] = t.get('hbm_bytes_per_launch')
+        roofline['traffic_source'] = 'profiles/r01_pmc_traffic.json'
       if 'wgrad' in fam:
         wsec, wcnt = fam['wgrad']
         wfl = fl['wgrad'] * B * args.steps
