@@ -56,11 +56,16 @@ struct ConvArgs {
 // {4-11,16-19,28-31} (+32), the 8 lanes of k-group g land on the even slots
 // and the 8 lanes of k-group g+1 (next 16-B chunk) on the odd slots: no bank
 // conflicts.  (An odd pitch gives 2-way conflicts on every fragment read.)
-constexpr int kPitchB4 = 144;         // 128 + 16 bf16: 18 slots per row (KS = 4)
-constexpr int kPitchB2 = 80;          // 64 + 16 bf16: 10 slots per row (KS = 2)
+// Weight stages live in a 3-deep LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: lane-linear 1 KiB per wave-instruction, so rows are
+// unpadded) and XOR-swizzled per 16-byte chunk instead: chunk c of row n sits at
+// slot c ^ swz(n), swz = (n >> 1) & 7 for 128-B rows, n & 15 for 256-B rows ->
+// the 16 rows of a fragment read hit 16 distinct bank slots, and the two
+// k-groups of a ds_read_b128 lane group stay disjoint.
+constexpr int kNBufB = 3;
 constexpr int kScrPitch = 68;         // fp32 epilogue scratch pitch
-constexpr int ldsB_bytes(int ks) {  // double-buffered weight stage
-  return 2 * 64 * (ks == 4 ? kPitchB4 : kPitchB2) * 2;
+constexpr int ldsB_bytes(int ks) {  // ring of 64 x (32*ks) bf16 stages
+  return kNBufB * 64 * (32 * ks) * 2;
 }
 constexpr int kScratchBytes = 4 * 16 * kScrPitch * 4;
 
@@ -72,8 +77,10 @@ template <int R, int MT, int KS, bool UNI>
 __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TM = 64 * MT;
-  constexpr int kPitchB = KS == 4 ? kPitchB4 : kPitchB2;
-  constexpr int FS = 4 * KS;  // 16-byte K groups per stage (16 or 8)
+  constexpr int FS = 4 * KS;        // 16-byte K groups per stage (16 or 8)
+  constexpr int kRowB = FS * 8;     // bf16 elements per B row in LDS (no pad)
+  constexpr int kBufB = 64 * kRowB; // elements per ring slot
+  constexpr int NDMA = (kBufB * 2 / 1024) / 4;  // DMA instructions per wave/stage
   uint16_t* ldsA = reinterpret_cast<uint16_t*>(smem);
   uint16_t* ldsB = ldsA + a.ldsA_elems;
 
@@ -117,44 +124,42 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int totalA = R * regionRows * a.c8;
-  // B staging: a stage is 64 rows x FS 16-byte groups; thread -> group
-  // f = tid % FS, rows tid / FS + (256 / FS) * i for i < FS / 4 (named
-  // registers, not arrays: keeps the prefetch out of scratch)
-  constexpr int NBL = FS / 4;           // loads per thread per stage (4 or 2)
-  constexpr int RSTEP = 256 / FS;       // row step between a thread's loads
-  const int brow = tid / FS;
-  const int bf = tid % FS;
-  const uint16_t* bsrc = wp + (long long)(n0 + brow) * a.Kpack + bf * 8;
-  const long long bstep = (long long)RSTEP * a.Kpack;
-  const int bdst = brow * kPitchB + bf * 8;
-  constexpr int kBStepDst = RSTEP * kPitchB;
-  constexpr int kBufB = 64 * kPitchB;  // elements per B buffer
-  uint4 b0, b1, b2, b3;
-  b2 = b3 = make_uint4(0u, 0u, 0u, 0u);
-#define CG_LOAD_B(koff)                                                     \
-  do {                                                                      \
-    b0 = *reinterpret_cast<const uint4*>(bsrc + (koff));                    \
-    b1 = *reinterpret_cast<const uint4*>(bsrc + (koff) + bstep);            \
-    if (NBL == 4) {                                                         \
-      b2 = *reinterpret_cast<const uint4*>(bsrc + (koff) + 2 * bstep);      \
-      b3 = *reinterpret_cast<const uint4*>(bsrc + (koff) + 3 * bstep);      \
-    }                                                                       \
-  } while (0)
-#define CG_STORE_B(buf)                                                     \
-  do {                                                                      \
-    *reinterpret_cast<uint4*>((buf) + bdst) = b0;                           \
-    *reinterpret_cast<uint4*>((buf) + bdst + kBStepDst) = b1;               \
-    if (NBL == 4) {                                                         \
-      *reinterpret_cast<uint4*>((buf) + bdst + 2 * kBStepDst) = b2;         \
-      *reinterpret_cast<uint4*>((buf) + bdst + 3 * kBStepDst) = b3;         \
-    }                                                                       \
-  } while (0)
+  // B staging by LDS-DMA: wave w issues instructions j = w*NDMA + i, each
+  // writing LDS bytes [j KiB, (j+1) KiB) of the ring slot; lane L lands at byte
+  // j*1024 + L*16 = (row, slot c'), and fetches global chunk c = c' ^ swz(row).
+  const uint16_t* dsrc[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int p = ((wave * NDMA + i) * 1024 + lane * 16) / 2;  // element offset
+    const int row = p / kRowB;
+    const int cs = (p % kRowB) / 8;
+    const int c = cs ^ (KS == 4 ? (row & 15) : ((row >> 1) & 7));
+    dsrc[i] = wp + (long long)(n0 + row) * a.Kpack + c * 8;
+  }
   const int nstages = a.Fp / FS;
+  const int total_stages = a.nchunks * nstages;
+  auto issue_dma = [&](int gs) {
+    // packed weights are contiguous over (chunk, stage): offset gs * FS * 8
+    uint16_t* slot = ldsB + (gs % kNBufB) * kBufB;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(dsrc[i] +
+                                                          (long long)gs * FS * 8),
+          (__attribute__((address_space(3))) void*)(slot +
+                                                    (wave * NDMA + i) * 512),
+          16, 0, 0);
+  };
+  // fragment-read offsets of this lane inside a ring slot (swizzled chunk)
+  const int swz = KS == 4 ? r16 : ((r16 >> 1) & 7);
+  int boff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    boff[ks] = r16 * kRowB + (((4 * ks + g) ^ swz) * 8);
+  issue_dma(0);
+  if (total_stages > 1) issue_dma(1);
 
   for (int cc = 0; cc < a.nchunks; ++cc) {
-    // first B stage of this chunk: issue the loads before touching LDS so
-    // their latency overlaps the A staging below
-    CG_LOAD_B((long long)cc * a.Fp * 8);
     __syncthreads();  // previous chunk's fragment reads are done
     // ---- stage the source window of this channel chunk ------------------
     if (a.nseg == 1) {
@@ -227,7 +232,6 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
         *reinterpret_cast<uint4*>(ldsA + row * a.pitchA + q8 * 8) = v;
       }
     }
-    CG_STORE_B(ldsB);
     __syncthreads();
 
     // Flattened K position inside the chunk: 16-byte group f = 4*kstep + g.
@@ -239,10 +243,18 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
       int q8l = UNI ? 0 : g;  // c8 >= 4
       const int goff = UNI ? g * 8 : 0;
       for (int s = 0; s < nstages; ++s) {
-        const uint16_t* curB = ldsB + (s & 1) * kBufB;
-        const bool more = s + 1 < nstages;
-        if (more)  // prefetch the next weight stage into registers
-          CG_LOAD_B(((long long)cc * a.Fp + FS * (s + 1)) * 8);
+        const int gs = cc * nstages + s;
+        // stage gs has landed once all but this wave's newest NDMA DMAs are
+        // done (only DMA(gs+1) may stay in flight); the barrier then (a) makes
+        // every wave's part of stage gs visible and (b) guarantees slot
+        // (gs+2) % 3 == (gs-1) % 3 is no longer being read before it is refilled
+        if (gs + 1 < total_stages)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (gs + 2 < total_stages) issue_dma(gs + 2);
+        const uint16_t* curB = ldsB + (gs % kNBufB) * kBufB;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int t = tap < a.taps ? tap : a.taps - 1;  // padded K: B is zero
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
             bfrag[nt] = *reinterpret_cast<const bf16x8*>(
-                curB + (nt * 16 + r16) * kPitchB + (4 * ks + g) * 8);
+                curB + nt * 16 * kRowB + boff[ks]);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(
@@ -270,11 +282,6 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
             q8l -= a.c8;
             ++tap;
           }
-        }
-        if (more) {
-          uint16_t* nxtB = ldsB + ((s + 1) & 1) * kBufB;
-          CG_STORE_B(nxtB);
-          __syncthreads();
         }
       }
     }

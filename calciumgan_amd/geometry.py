@@ -9,7 +9,7 @@ from collections import namedtuple
 
 NUM_CONVS = 5
 LDS_BYTES = 160 * 1024
-_LDS_B = 2 * 64 * 80 * 2  # smallest (64-wide) double-buffered weight stage
+_LDS_B = 3 * 64 * 64 * 2  # smallest (64-wide stages) 3-deep LDS-DMA weight ring
 _SCRATCH = 4 * 16 * 68 * 4
 
 
@@ -18,12 +18,12 @@ def round_up(v, m):
 
 
 def pitch(channels):
-  """Channel pitch of a bf16 activation: multiple of 8 (16-byte rows), at least
-  32 (smallest MFMA K chunk); above 128 a multiple of 32 so a 32/64 chunk
-  divides it."""
-  if channels <= 128:
-    return max(32, round_up(channels, 8))
-  return round_up(channels, 32)
+  """Channel pitch of a bf16 activation: a multiple of 32, so the 32-channel
+  chunk (CK = 32: 16-byte rows, uniform K walk, three workgroups per CU)
+  always divides it.  102 -> 128: the 23 % extra (zero) K on the C = 102 layers
+  is cheaper than the single-chunk CK = 104 path (1 workgroup per CU, measured
+  0.49 vs 0.9 PFLOP/s)."""
+  return max(32, round_up(channels, 32))
 
 
 def calculate_noise_shape(output_shape, noise_dim, num_convolutions, strides):

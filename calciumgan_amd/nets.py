@@ -143,7 +143,7 @@ def _transpose_phases(k, pad_left):
   return out
 
 
-CK_TARGET = {1: 64, 2: 32}  # preferred channel chunk per source stride
+CK_TARGET = {1: 32, 2: 32}  # preferred channel chunk per source stride
 
 
 def _ck_for(Cx, stride, taps, Lu):
@@ -200,10 +200,11 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
   return d
 
 
-# Row-tile choice by measurement: the best of {256, 128, 64}-row tiles depends
-# on how the launch quantises over 256 CUs and on LDS residency, so each
-# distinct launch geometry is timed once (3 runs per candidate, a few hundred
-# microseconds in total) when its descriptor is first built.  Every candidate
+# Row-tile / weight-stage choice by measurement: the best of {256, 128, 64}-row
+# tiles x {64, 128}-wide weight stages depends on how the launch quantises over
+# 256 CUs and on LDS residency, so each distinct launch geometry is timed once
+# (3 runs per candidate, about a millisecond in total) when its descriptor is
+# first built.  Every candidate
 # computes bit-identical results (same K order per output element).
 _TILE_CACHE = {}
 _AUTOTUNE = __import__('os').environ.get('CALCIUMGAN_AUTOTUNE', '1') != '0'
@@ -226,6 +227,7 @@ def _autotune_tile(d):
         ok = False
       if ok and geo.lds_bytes(d.CK, d.stride, d.taps, d.Lu, tm) <= geo.LDS_BYTES:
         cands.append(small)
+    cands = [(small, ks) for small in cands for ks in (2, 4)]
     times = {}
     y_saved = d.y
     scratch = None
@@ -235,8 +237,9 @@ def _autotune_tile(d):
       nbytes = d.nB * d.Ly * d.Cy * (4 if d.out_f32 else 2)
       scratch = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
       d.y = scratch.data_ptr()
-    for small in cands:
+    for small, ks in cands:
       d.small_tile = small
+      d.stage_ksteps = ks
       if lib.cg_swconv(ctypes.byref(d), st) != 0:
         continue
       s = torch.cuda.Event(enable_timing=True)
@@ -246,14 +249,14 @@ def _autotune_tile(d):
         lib.cg_swconv(ctypes.byref(d), st)
       e.record()
       e.synchronize()
-      times[small] = s.elapsed_time(e)
+      times[(small, ks)] = s.elapsed_time(e)
     d.y = y_saved
     del scratch
     if not times:
       return
     best = min(times, key=times.get)
     _TILE_CACHE[key] = best
-  d.small_tile = best
+  d.small_tile, d.stage_ksteps = best
 
 
 def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,

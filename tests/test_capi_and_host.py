@@ -90,7 +90,7 @@ def test_layer_tables_match_survey_appendix_b():
   assert [(l.cin, l.cout, l.lin, l.lout) for l in g] == [
       (32, 320, 64, 128), (320, 256, 128, 256), (256, 192, 256, 512),
       (192, 128, 512, 1024), (128, 102, 1024, 2048)]
-  assert d[0].cinp == 104 and g[-1].coutp == 104
+  assert d[0].cinp == 128 and g[-1].coutp == 128
   assert geo.pitch(6) == 32 and geo.pitch(320) == 320 and geo.pitch(130) == 160
 
 
