@@ -7,10 +7,16 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libcalciumgan_hip.so')
+# CALCIUMGAN_HIP_LIB points at another build of the same C ABI (development)
+LIB_PATH = os.environ.get('CALCIUMGAN_HIP_LIB') or os.path.join(
+    _HERE, 'csrc', 'libcalciumgan_hip.so')
 
 CG_EINVAL = 100001
 EPI_NONE, EPI_LRELU, EPI_MASK, EPI_SIGMOID = 0, 1, 2, 3
+# CG_TILE_*: value -> (rows, cols, mfma rows)
+TILES = {0: (256, 64, 16), 1: (64, 64, 16), 2: (128, 64, 16),
+         3: (256, 64, 32), 4: (128, 64, 32), 5: (256, 128, 32),
+         6: (128, 128, 32)}
 
 c_vp = C.c_void_p
 c_i = C.c_int
@@ -32,7 +38,7 @@ class ConvDesc(C.Structure):
       ('nphase', c_i),
       ('w_phase_stride', c_ll),
       ('off_phase_step', c_i), ('yoff_phase_step', c_i),
-      ('small_tile', c_i),
+      ('tile', c_i),
       ('stage_ksteps', c_i),
       ('rowsumsq', c_vp),
   ]
@@ -66,6 +72,7 @@ class WgradDesc(C.Structure):
 # name -> argtypes (restype is int unless listed in _RESTYPES)
 SIGNATURES = {
     'cg_abi_version': [],
+    'cg_tile_shape': [c_i, C.POINTER(c_i), C.POINTER(c_i)],
     'cg_swconv': [C.POINTER(ConvDesc), c_vp],
     'cg_packed_elems': [c_i, c_i, c_i, c_i],
     'cg_pack_weights': [C.POINTER(PackDesc), c_vp],

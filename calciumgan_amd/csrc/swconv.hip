@@ -18,10 +18,12 @@
 //     free), and the channel chunk CK bounds LDS use.
 //   * the weight operand is pre-packed (cg_pack_weights) in exactly the K order
 //     the kernel walks, so a B stage is a contiguous 256-B-per-row copy.
-//   * block = 256 threads = 4 waves stacked along M; wave tile (16*MT) x 64,
-//     v_mfma_f32_16x16x32_bf16, fp32 accumulate; epilogue goes through LDS so
-//     global stores are 16-byte and row-contiguous, with bias / LeakyReLU /
-//     LeakyReLU-derivative mask / sigmoid fused.
+//   * block = 256 threads = 4 waves, 4x1 or 2x2 over (M, N); wave tile
+//     (MF*MT) x 64 on v_mfma_f32_16x16x32_bf16 (MF = 16) or
+//     v_mfma_f32_32x32x16_bf16 (MF = 32), fp32 accumulate; the 2x2 layout
+//     shares one source window between two 64-column halves.  The epilogue
+//     goes through LDS so global stores are 16-byte and row-contiguous, with
+//     bias / LeakyReLU / LeakyReLU-derivative mask / sigmoid fused.
 #include <type_traits>
 
 #include "cg_common.h"
@@ -48,14 +50,17 @@ struct ConvArgs {
   int log2c8;  // log2(c8) when c8 is a power of two, else -1
   long long w_phase_stride;
   int off_phase_step, yoff_phase_step;
-  int gm, gn, gp;  // logical grid: row tiles, 64-col tiles, phases
+  int gm, gn, gp;  // logical grid: row tiles, column tiles, phases
 };
 
-// LDS row pitches are 2*odd 16-byte slots: with the MFMA operand map (lane ->
-// row l&15, k-group l>>4) and ds_read_b128's lane groups {0-3,12-15,20-27},
-// {4-11,16-19,28-31} (+32), the 8 lanes of k-group g land on the even slots
-// and the 8 lanes of k-group g+1 (next 16-B chunk) on the odd slots: no bank
-// conflicts.  (An odd pitch gives 2-way conflicts on every fragment read.)
+// LDS row pitches, 16x16x32: 2*odd 16-byte slots: with the MFMA operand map
+// (lane -> row l&15, k-group l>>4) and ds_read_b128's lane groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32), the 8 lanes of k-group g land on
+// the even slots and the 8 lanes of k-group g+1 (next 16-B chunk) on the odd
+// slots: no bank conflicts.  (An odd pitch gives 2-way conflicts there.)
+// 32x32x16 (lane -> row l&31, k-group l>>5): the 16 lanes of a group share one
+// k-group and cover 16 rows that are distinct mod 16, so the pitch is an ODD
+// number of slots (row r -> slot r*odd mod 16, a permutation).
 // Weight stages live in a 3-deep LDS ring filled by LDS-DMA
 // (global_load_lds_dwordx4: lane-linear 1 KiB per wave-instruction, so rows are
 // unpadded) and XOR-swizzled per 16-byte chunk instead: chunk c of row n sits at
@@ -64,31 +69,45 @@ struct ConvArgs {
 // k-groups of a ds_read_b128 lane group stay disjoint.
 constexpr int kNBufB = 3;
 constexpr int kScrPitch = 68;         // fp32 epilogue scratch pitch
-constexpr int ldsB_bytes(int ks) {  // ring of 64 x (32*ks) bf16 stages
-  return kNBufB * 64 * (32 * ks) * 2;
+constexpr int ldsB_bytes(int ks, int tn) {  // ring of tn x (32*ks) bf16 stages
+  return kNBufB * tn * (32 * ks) * 2;
 }
 constexpr int kScratchBytes = 4 * 16 * kScrPitch * 4;
 
 // UNI: 4 | c8, the K walk is wave-uniform (see the chunk loop).
-// R: source stride.  MT: 16-row subtiles per wave (tile = 64*MT rows).  KS:
-// MFMA K-steps per weight stage (4: 64x128 stages; 2: 64x64 stages, half the
-// LDS so stride-2 windows still fit two workgroups per CU).
-template <int R, int MT, int KS, bool UNI>
-__global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
+// R: source stride.  MF: MFMA rows (16: 16x16x32, 32: 32x32x16).  WGN: waves
+// along N (1: 4x1 waves, 64-column tiles; 2: 2x2 waves, 128-column tiles that
+// share one source window).  MT: MF-row subtiles per wave (tile =
+// (4/WGN)*MT*MF rows).  KS: MFMA K-steps per weight stage (4: 128-deep stages;
+// 2: 64-deep stages, half the LDS so stride-2 windows still fit two
+// workgroups per CU).  (The 128 x 64 wave tile holds 128 accumulator
+// registers: the second launch-bound argument keeps the rest within 128 so
+// two workgroups share a CU.)
+template <int R, int MF, int WGN, int MT, int KS, bool UNI>
+__global__ __launch_bounds__(256, (MF == 32 && MT == 4) ? 2 : 1) void
+swconv_kernel(ConvArgs a) {
+  static_assert(MF == 16 || (MF == 32 && UNI), "32x32x16 needs the uniform K walk");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int TM = 64 * MT;
+  constexpr int WGM = 4 / WGN;
+  constexpr int TM = WGM * MT * MF;
+  constexpr int TN = 64 * WGN;
+  constexpr int NT = 64 / MF;       // MF-column subtiles per wave (4 or 2)
+  constexpr int KH = MF / 16;       // MFMAs per 32-deep K-step (1 or 2)
   constexpr int FS = 4 * KS;        // 16-byte K groups per stage (16 or 8)
   constexpr int kRowB = FS * 8;     // bf16 elements per B row in LDS (no pad)
-  constexpr int kBufB = 64 * kRowB; // elements per ring slot
+  constexpr int kBufB = TN * kRowB; // elements per ring slot
   constexpr int NDMA = (kBufB * 2 / 1024) / 4;  // DMA instructions per wave/stage
+  using acc_t = typename std::conditional<MF == 16, f32x4, f32x16>::type;
   uint16_t* ldsA = reinterpret_cast<uint16_t*>(smem);
   uint16_t* ldsB = ldsA + a.ldsA_elems;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int r16 = lane & 15;
-  const int g = lane >> 4;
+  const int wm = wave / WGN;        // wave position along M / N
+  const int wn = wave % WGN;
+  const int rM = lane & (MF - 1);   // operand row / column of this lane
+  const int g = lane / MF;          // its 16-byte k-group inside one MFMA
   // XCD-aware mapping: the gn*gp workgroups that share one row tile's source
   // window get linear ids congruent mod 8 (same XCD / L2) and adjacent in
   // dispatch order; speed only, results do not depend on placement.
@@ -105,23 +124,25 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
   const int off = a.off + phase * a.off_phase_step;
   const int y_off = a.y_off + phase * a.yoff_phase_step;
   const int m0 = bm * TM;
-  const int n0 = bn * 64;
+  const int n0 = bn * TN;
   const int regionRows = a.nseg * a.WR;
 
   int rowbase[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int i = wave * 16 * MT + mt * 16 + r16;
+    const int i = (wm * MT + mt) * MF + rM;
     const int seg = i >> a.log2S;
     const int ui = i & (a.S - 1);
     rowbase[mt] = (seg * a.WR + ui) * a.pitchA;
   }
 
-  f32x4 acc[MT][4];
+  acc_t acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < MF * MF / 64; ++r) acc[mt][nt][r] = 0.f;
 
   const int totalA = R * regionRows * a.c8;
   // B staging by LDS-DMA: wave w issues instructions j = w*NDMA + i, each
@@ -150,12 +171,16 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
                                                     (wave * NDMA + i) * 512),
           16, 0, 0);
   };
-  // fragment-read offsets of this lane inside a ring slot (swizzled chunk)
-  const int swz = KS == 4 ? r16 : ((r16 >> 1) & 7);
-  int boff[KS];
+  // fragment-read offsets of this lane inside a ring slot (swizzled chunk);
+  // MFMA kh of K-step ks reads k-group 4*ks + 2*kh + g
+  const int swz = KS == 4 ? (rM & 15) : ((rM >> 1) & 7);
+  int boff[KS][KH];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
-    boff[ks] = r16 * kRowB + (((4 * ks + g) ^ swz) * 8);
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+      boff[ks][kh] =
+          (wn * 64 + rM) * kRowB + (((4 * ks + 2 * kh + g) ^ swz) * 8);
   issue_dma(0);
   if (total_stages > 1) issue_dma(1);
 
@@ -263,19 +288,27 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
             aoff = ((t & 1) * regionRows + (t >> 1)) * a.pitchA + q8l * 8;
           else
             aoff = t * a.pitchA + q8l * 8;
-          bf16x8 bfrag[4];
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            bfrag[nt] = *reinterpret_cast<const bf16x8*>(
-                curB + nt * 16 * kRowB + boff[ks]);
+          for (int kh = 0; kh < KH; ++kh) {
+            bf16x8 bfrag[NT];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(
-                ldsA + (rowbase[mt] + goff) + aoff);
+            for (int nt = 0; nt < NT; ++nt)
+              bfrag[nt] = *reinterpret_cast<const bf16x8*>(
+                  curB + nt * MF * kRowB + boff[ks][kh]);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  afrag, bfrag[nt], acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) {
+              const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(
+                  ldsA + (rowbase[mt] + goff) + aoff + kh * 16);
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (MF == 16)
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                      afrag, bfrag[nt], acc[mt][nt], 0, 0, 0);
+                else
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                      afrag, bfrag[nt], acc[mt][nt], 0, 0, 0);
+              }
+            }
           }
           q8l += 4;
           if (q8l >= a.c8) {
@@ -298,22 +331,34 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
   for (int half = 0; half < 2; ++half)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int n = n0 + ecol + 8 * half + e;
+      const int n = n0 + wn * 64 + ecol + 8 * half + e;
       bv[half][e] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
     }
+  // 16 rows x 64 columns of the wave tile at a time
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+  for (int mh = 0; mh < MT * KH; ++mh) {
+    const int mt = mh / KH;
+    const int h = mh % KH;  // 16-row half of a 32-row subtile
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
+      if constexpr (MF == 16) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        scr[(4 * g + r) * kScrPitch + nt * 16 + r16] = acc[mt][nt][r];
+        for (int r = 0; r < 4; ++r)
+          scr[(4 * g + r) * kScrPitch + nt * 16 + rM] = acc[mt][nt][r];
+      } else {
+        // 32x32 accumulator: register j <-> row 8*(j/4) + 4*g + j%4, column rM
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          scr[((j >> 2) * 8 + 4 * g + (j & 3)) * kScrPitch + nt * 32 + rM] =
+              acc[mt][nt][8 * h + j];
+      }
+    }
     // the scratch is private to this wave and a wave's LDS ops complete in
     // order: a wave barrier (no s_barrier) is enough
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int i = wave * 16 * MT + mt * 16 + erow;
+    const int i = (wm * MT + mt) * MF + h * 16 + erow;
     const int m = m0 + i;
     if (m < a.M) {
       const int b = m / a.Lu;
@@ -322,7 +367,7 @@ __global__ __launch_bounds__(256) void swconv_kernel(ConvArgs a) {
           ((long long)b * a.Ly + (long long)a.y_stride * u + y_off) * a.Cy;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        const int n = n0 + ecol + 8 * half;
+        const int n = n0 + wn * 64 + ecol + 8 * half;
         if (n < a.Cy) {
           float v[8];
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(
@@ -455,7 +500,7 @@ extern "C" long long cg_packed_elems(int N, int taps, int Cx, int CK) {
   if (CK < 32 || CK % 8 || Cx % CK || taps < 1 || N < 1) return -1;
   const int c8 = CK / 8;
   const int Fp = (taps * c8 + 15) / 16 * 16;
-  const long long Npad = (N + 63) / 64 * 64;
+  const long long Npad = (N + 127) / 128 * 128;  // whole 128-column tiles
   return Npad * (long long)(Cx / CK) * Fp * 8;
 }
 
@@ -534,27 +579,50 @@ extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {
   CG_LAUNCH_CHECK();
 }
 
-template <int R, int MT, int KS, bool UNI>
+template <int R, int MF, int WGN, int MT, int KS, bool UNI>
 static int launch_swconv1(const ConvArgs& a, dim3 grid, size_t lds,
                           hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&swconv_kernel<R, MT, KS, UNI>),
+        reinterpret_cast<const void*>(&swconv_kernel<R, MF, WGN, MT, KS, UNI>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((swconv_kernel<R, MT, KS, UNI>), grid, dim3(256), lds,
-                     stream, a);
+  hipLaunchKernelGGL((swconv_kernel<R, MF, WGN, MT, KS, UNI>), grid, dim3(256),
+                     lds, stream, a);
   CG_LAUNCH_CHECK();
 }
 
-template <int R, int MT, int KS>
+template <int R, int MF, int WGN, int MT, int KS>
 static int launch_swconv(const ConvArgs& a, dim3 grid, size_t lds,
                          hipStream_t stream) {
-  if ((a.c8 & 3) == 0) return launch_swconv1<R, MT, KS, true>(a, grid, lds, stream);
-  return launch_swconv1<R, MT, KS, false>(a, grid, lds, stream);
+  if ((a.c8 & 3) == 0)
+    return launch_swconv1<R, MF, WGN, MT, KS, true>(a, grid, lds, stream);
+  if constexpr (MF == 16)
+    return launch_swconv1<R, MF, WGN, MT, KS, false>(a, grid, lds, stream);
+  return CG_EINVAL;
+}
+
+// cg_conv_desc.tile -> (MFMA rows, waves along N, subtiles per wave)
+struct TileCfg { int mf, wgn, mt; };
+static const TileCfg kTileCfgs[CG_NUM_TILES] = {
+    {16, 1, 4},  // CG_TILE_256x64
+    {16, 1, 1},  // CG_TILE_64x64
+    {16, 1, 2},  // CG_TILE_128x64
+    {32, 1, 2},  // CG_TILE_256x64_M32
+    {32, 1, 1},  // CG_TILE_128x64_M32
+    {32, 2, 4},  // CG_TILE_256x128_M32
+    {32, 2, 2},  // CG_TILE_128x128_M32
+};
+
+extern "C" int cg_tile_shape(int tile, int* rows, int* cols) {
+  if (tile < 0 || tile >= CG_NUM_TILES) return CG_EINVAL;
+  const TileCfg& t = kTileCfgs[tile];
+  if (rows) *rows = (4 / t.wgn) * t.mt * t.mf;
+  if (cols) *cols = 64 * t.wgn;
+  return 0;
 }
 
 extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
@@ -568,7 +636,11 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   if (d->epilogue == CG_EPI_MASK && !d->mask_src) return CG_EINVAL;
   if (d->shifts && d->seg_size < 1) return CG_EINVAL;
   const int R = d->stride;
-  const int TM = d->small_tile == 1 ? 64 : (d->small_tile == 2 ? 128 : 256);
+  if (d->tile < 0 || d->tile >= CG_NUM_TILES) return CG_EINVAL;
+  const TileCfg tc = kTileCfgs[d->tile];
+  const int TM = (4 / tc.wgn) * tc.mt * tc.mf;
+  const int TN = 64 * tc.wgn;
+  if (tc.mf == 32 && (d->CK / 8) % 4) return CG_EINVAL;  // uniform K walk only
   int S;
   if (d->Lu >= TM) {
     if (d->Lu % TM) return CG_EINVAL;
@@ -596,7 +668,10 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   a.Fp = (d->taps * a.c8 + 15) / 16 * 16;
   a.nstages = a.Fp / 16;  // 128-wide stages; the kernel derives its own
   a.Kpack = (long long)a.nchunks * a.Fp * 8;
-  a.pitchA = d->CK + 8 * ((6 - (a.c8 & 3)) & 3);  // slots == 2 (mod 4)
+  if (tc.mf == 16)
+    a.pitchA = d->CK + 8 * ((6 - (a.c8 & 3)) & 3);  // slots == 2 (mod 4)
+  else
+    a.pitchA = d->CK + 8;                            // 4 | c8: odd slots
   a.S = S; a.log2S = ilog2(S); a.nseg = TM / S;
   a.WR = S + d->taps / R - 1;
   if (d->rowsumsq && a.nseg != 1) return CG_EINVAL;  // one sample per tile
@@ -614,23 +689,27 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   // wide (128-wide) one
   const size_t cu_lds = 160 * 1024;
   int ks = 4;
-  if (cu_lds / (ldsA_bytes + ldsB_bytes(2)) > cu_lds / (ldsA_bytes + ldsB_bytes(4)))
+  if (cu_lds / (ldsA_bytes + ldsB_bytes(2, TN)) >
+      cu_lds / (ldsA_bytes + ldsB_bytes(4, TN)))
     ks = 2;
   if (d->stage_ksteps == 2 || d->stage_ksteps == 4) ks = d->stage_ksteps;
-  const size_t lds = ldsA_bytes + ldsB_bytes(ks);
+  const size_t lds = ldsA_bytes + ldsB_bytes(ks, TN);
   if (lds > 160 * 1024) return CG_EINVAL;
   a.gm = (a.M + TM - 1) / TM;
-  a.gn = (d->N + 63) / 64;
+  a.gn = (d->N + TN - 1) / TN;
   a.gp = d->nphase;
   dim3 grid((unsigned)(((a.gm + 7) / 8) * 8 * a.gn * a.gp));
   hipStream_t s = (hipStream_t)stream;
-  const int mt = TM / 64;
-#define CG_DISPATCH(RR, MM, KK) \
-  if (R == RR && mt == MM && ks == KK) return launch_swconv<RR, MM, KK>(a, grid, lds, s);
-  CG_DISPATCH(1, 4, 4) CG_DISPATCH(1, 2, 4) CG_DISPATCH(1, 1, 4)
-  CG_DISPATCH(2, 4, 4) CG_DISPATCH(2, 2, 4) CG_DISPATCH(2, 1, 4)
-  CG_DISPATCH(1, 4, 2) CG_DISPATCH(1, 2, 2) CG_DISPATCH(1, 1, 2)
-  CG_DISPATCH(2, 4, 2) CG_DISPATCH(2, 2, 2) CG_DISPATCH(2, 1, 2)
+#define CG_DISPATCH(RR, FF, WW, MM, KK)                                   \
+  if (R == RR && tc.mf == FF && tc.wgn == WW && tc.mt == MM && ks == KK) \
+    return launch_swconv<RR, FF, WW, MM, KK>(a, grid, lds, s);
+#define CG_DISPATCH_RK(FF, WW, MM)                              \
+  CG_DISPATCH(1, FF, WW, MM, 4) CG_DISPATCH(2, FF, WW, MM, 4) \
+  CG_DISPATCH(1, FF, WW, MM, 2) CG_DISPATCH(2, FF, WW, MM, 2)
+  CG_DISPATCH_RK(16, 1, 4) CG_DISPATCH_RK(16, 1, 1) CG_DISPATCH_RK(16, 1, 2)
+  CG_DISPATCH_RK(32, 1, 2) CG_DISPATCH_RK(32, 1, 1)
+  CG_DISPATCH_RK(32, 2, 4) CG_DISPATCH_RK(32, 2, 2)
+#undef CG_DISPATCH_RK
 #undef CG_DISPATCH
   return CG_EINVAL;
 }

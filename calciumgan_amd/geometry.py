@@ -9,7 +9,7 @@ from collections import namedtuple
 
 NUM_CONVS = 5
 LDS_BYTES = 160 * 1024
-_LDS_B = 3 * 64 * 64 * 2  # smallest (64-wide stages) 3-deep LDS-DMA weight ring
+_LDS_B = 3 * 64 * 64 * 2  # smallest (64 x 64) 3-deep LDS-DMA weight ring slot set
 _SCRATCH = 4 * 16 * 68 * 4
 
 
@@ -41,7 +41,7 @@ def same_padding_left(kernel_size, strides):
 
 def tile_rows(Lu, M, n_tiles_n):
   """Row tile of cg_swconv: 256 when the per-sample length allows it and the
-  launch still has >= 256 workgroups, else 64.  Returns (small_tile, TM)."""
+  launch still has >= 256 workgroups, else 64.  Returns (CG_TILE_* value, TM)."""
   def ok(tm):
     return (Lu % tm == 0) if Lu >= tm else (tm % Lu == 0)
   if ok(256) and (M // 256) * n_tiles_n >= 256:
@@ -55,14 +55,18 @@ def tile_rows(Lu, M, n_tiles_n):
       'multiple of 64)'.format(Lu))
 
 
-def lds_bytes(CK, stride, taps, Lu, TM):
+def lds_bytes(CK, stride, taps, Lu, TM, TN=64, mfma_rows=16):
+  """Smallest dynamic LDS of a cg_swconv launch (64-deep weight stages)."""
   c8 = CK // 8
-  pitch_a = CK + 8 * ((6 - (c8 & 3)) & 3)  # 16-byte slots == 2 (mod 4)
+  if mfma_rows == 16:
+    pitch_a = CK + 8 * ((6 - (c8 & 3)) & 3)  # 16-byte slots == 2 (mod 4)
+  else:
+    pitch_a = CK + 8                         # odd slot count (4 | c8)
   S = min(Lu, TM)
   nseg = TM // S
   WR = S + taps // stride - 1
   a = max(stride * nseg * WR * pitch_a * 2, _SCRATCH)
-  return round_up(a, 16) + _LDS_B
+  return round_up(a, 16) + _LDS_B * (TN // 64)
 
 
 ConvLayer = namedtuple('ConvLayer', 'cin cout lin lout cinp coutp')

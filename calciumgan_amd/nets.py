@@ -150,7 +150,7 @@ def _ck_for(Cx, stride, taps, Lu):
   """Channel chunk of a packed operand: a divisor of the pitch, multiple of 8,
   >= 32, valid for both row tiles the launcher may pick.  Preference: the chunk
   that keeps one workgroup's LDS under half the CU (two resident workgroups
-  hide each other's staging): 32 for stride-2 windows, 64 for stride-1."""
+  hide each other's staging): 32."""
   cands = [d for d in range(32, Cx + 1, 8) if Cx % d == 0]
   tgt = CK_TARGET[stride]
   pref = sorted(cands, key=lambda d: (d > tgt, abs(d - tgt)))
@@ -195,20 +195,21 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
   # workgroups per CU (measured +10 % over 256-row tiles at two per CU)
   if small == 0 and stride == 2 and CK <= 32 and Lu % 128 == 0:
     small = 2
-  d.small_tile = small
+  d.tile = small
   _autotune_tile(d)
   return d
 
 
-# Row-tile / weight-stage choice by measurement: the best of {256, 128, 64}-row
-# tiles x {64, 128}-wide weight stages depends on how the launch quantises over
-# 256 CUs and on LDS residency, so each distinct launch geometry is timed once
-# (3 runs per candidate, about a millisecond in total) when its descriptor is
-# first built.  Every candidate
-# computes bit-identical results (same K order per output element).
+# Tile / weight-stage choice by measurement: the best of the CG_TILE_* shapes x
+# {64, 128}-deep weight stages depends on how the launch quantises over 256 CUs
+# and on LDS residency, so each distinct launch geometry is timed once (3 runs
+# per candidate, a few milliseconds in total) when its descriptor is first
+# built.  All candidates walk K in the same order; the 16x16x32 and 32x32x16
+# MFMA shapes may differ in the last f32 bit of a 32-deep partial sum, so a
+# process keeps ONE choice per geometry (and CALCIUMGAN_AUTOTUNE=0 pins the
+# static default for run-to-run bit reproducibility).
 _TILE_CACHE = {}
 _AUTOTUNE = __import__('os').environ.get('CALCIUMGAN_AUTOTUNE', '1') != '0'
-_TILE_ROWS = {0: 256, 2: 128, 1: 64}
 
 
 def _autotune_tile(d):
@@ -221,11 +222,16 @@ def _autotune_tile(d):
     lib = _lib.load()
     st = _stream()
     cands = []
-    for small, tm in _TILE_ROWS.items():
+    for small, (tm, tn, mf) in _lib.TILES.items():
       ok = (d.Lu % tm == 0) if d.Lu >= tm else (tm % d.Lu == 0)
       if d.rowsumsq and d.Lu < tm:
         ok = False
-      if ok and geo.lds_bytes(d.CK, d.stride, d.taps, d.Lu, tm) <= geo.LDS_BYTES:
+      if mf == 32 and d.CK % 32:
+        ok = False
+      if tn > 64 and d.N <= 64:
+        ok = False
+      if ok and geo.lds_bytes(d.CK, d.stride, d.taps, d.Lu, tm, tn,
+                              mf) <= geo.LDS_BYTES:
         cands.append(small)
     cands = [(small, ks) for small in cands for ks in (2, 4)]
     times = {}
@@ -238,7 +244,7 @@ def _autotune_tile(d):
       scratch = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
       d.y = scratch.data_ptr()
     for small, ks in cands:
-      d.small_tile = small
+      d.tile = small
       d.stage_ksteps = ks
       if lib.cg_swconv(ctypes.byref(d), st) != 0:
         continue
@@ -256,7 +262,7 @@ def _autotune_tile(d):
       return
     best = min(times, key=times.get)
     _TILE_CACHE[key] = best
-  d.small_tile, d.stage_ksteps = best
+  d.tile, d.stage_ksteps = best
 
 
 def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 1
+#define CG_ABI_VERSION 2
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -35,7 +35,22 @@ extern "C" {
 #define CG_EPI_MASK 2     /* y = acc * (mask_src > 0 ? 1 : alpha) */
 #define CG_EPI_SIGMOID 3  /* y = sigmoid(acc + bias) */
 
+/* workgroup tile of cg_swconv (rows x columns of y per workgroup); the _M32
+ * tiles run v_mfma_f32_32x32x16_bf16 and need CK % 32 == 0, the others
+ * v_mfma_f32_16x16x32_bf16.  Every tile gives the same result up to the f32
+ * summation order inside one 32-deep K-step. */
+#define CG_TILE_256x64 0
+#define CG_TILE_64x64 1
+#define CG_TILE_128x64 2
+#define CG_TILE_256x64_M32 3
+#define CG_TILE_128x64_M32 4
+#define CG_TILE_256x128_M32 5
+#define CG_TILE_128x128_M32 6
+#define CG_NUM_TILES 7
+
 int cg_abi_version(void);
+/* rows / columns of a CG_TILE_* value (host helper; CG_EINVAL if unknown) */
+int cg_tile_shape(int tile, int* rows, int* cols);
 
 /* ---------------------------------------------------------------------------
  * Sliding-window convolution as an implicit GEMM on MFMA (bf16 in, f32 acc).
@@ -58,11 +73,11 @@ int cg_abi_version(void);
  * `w` is the packed operand produced by cg_pack_weights for the same
  * (taps, Cx, CK).  Supported: stride in {1,2}; taps even when stride == 2;
  * Cx % CK == 0, CK % 8 == 0, CK >= 32; Lu a power-of-two divisor or any
- * multiple of the row tile (64 or 256).
+ * multiple of the row tile (cg_tile_shape).
  * ------------------------------------------------------------------------- */
 typedef struct cg_conv_desc {
   const void* x;        /* bf16 [nB][Lx][Cx] */
-  const void* w;        /* bf16 packed [ceil(N/64)*64][Kpack] per phase */
+  const void* w;        /* bf16 packed [ceil(N/128)*128][Kpack] per phase */
   void* y;              /* bf16 or f32 [nB][Ly][Cy] */
   const float* bias;    /* f32 [N] or NULL */
   const void* mask_src; /* bf16, geometry of y; CG_EPI_MASK only */
@@ -76,7 +91,7 @@ typedef struct cg_conv_desc {
   int nphase;
   long long w_phase_stride; /* elements */
   int off_phase_step, yoff_phase_step;
-  int small_tile;       /* 0: 256-row tiles, 1: 64-row tiles */
+  int tile;             /* CG_TILE_* */
   int stage_ksteps;     /* 0: choose; 2 or 4: MFMA K-steps per weight stage */
   float* rowsumsq;      /* optional f32 [nB]: += sum over (row, n) of y^2 per
                            sample (penalty norm, wgan_gp.py:49); needs Lu >= tile */

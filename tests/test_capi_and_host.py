@@ -34,16 +34,26 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert hasattr(lib, n), 'missing export ' + n
     assert n in _lib.SIGNATURES, 'no ctypes signature for ' + n
   assert sorted(_lib.SIGNATURES) == names
-  assert lib.cg_abi_version() == 1
+  assert lib.cg_abi_version() == 2
 
 
 def test_packed_elems_host_formula():
   lib = _lib.load()
-  # N rows padded to 64, K padded to 16 groups of 8 per channel chunk
-  assert lib.cg_packed_elems(64, 24, 104, 104) == 64 * 320 * 8
+  # N rows padded to 128, K padded to 16 groups of 8 per channel chunk
+  assert lib.cg_packed_elems(64, 24, 104, 104) == 128 * 320 * 8
   assert lib.cg_packed_elems(102, 1, 104, 104) == 128 * 16 * 8
-  assert lib.cg_packed_elems(320, 12, 256, 64) == 320 * 4 * 96 * 8
+  assert lib.cg_packed_elems(320, 12, 256, 64) == 384 * 4 * 96 * 8
   assert lib.cg_packed_elems(64, 24, 100, 50) == -1  # CK not multiple of 8
+
+
+def test_tile_table_matches_library():
+  lib = _lib.load()
+  import ctypes
+  for tile, (rows, cols, _) in _lib.TILES.items():
+    r, c = ctypes.c_int(), ctypes.c_int()
+    assert lib.cg_tile_shape(tile, ctypes.byref(r), ctypes.byref(c)) == 0
+    assert (r.value, c.value) == (rows, cols)
+  assert lib.cg_tile_shape(len(_lib.TILES), None, None) == _lib.CG_EINVAL
 
 
 def test_no_cpu_fallback_without_device():

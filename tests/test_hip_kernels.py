@@ -86,21 +86,93 @@ def test_conv_fwd_bitexact(nB, L, Ci, Co, k, seg, use_shift):
   assert float(got[:, :, Co:].abs().max()) == 0.0 if cop > Co else True
 
 
-@pytest.mark.parametrize('small', [0, 1])
-def test_conv_fwd_both_tiles_agree(small):
+ALL_TILES = [(t, ks) for t in sorted(_lib.TILES) for ks in (2, 4)]
+
+
+def _force_tile(d, tile, ks):
+  """Override the autotuned choice; skip when the shape does not admit the
+  tile (cg_swconv answers CG_EINVAL and launches nothing)."""
+  d.tile, d.stage_ksteps = tile, ks
+  rc = _lib.load().cg_swconv(ctypes.byref(d), H.stream())
+  if rc == _lib.CG_EINVAL:
+    pytest.skip('tile %d not admissible for this shape' % tile)
+  assert rc == 0
+
+
+@pytest.mark.parametrize('tile,ks', ALL_TILES)
+@pytest.mark.parametrize('nB,L,Ci,Co,k,seg', [(2, 1024, 64, 192, 24, 1),
+                                              (6, 128, 96, 102, 24, 2),
+                                              (3, 512, 32, 64, 8, 3)])
+def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg):
+  """Stride-2 forward with phase shuffle + bias + LeakyReLU on every workgroup
+  tile (both MFMA shapes, 4x1 and 2x2 waves) and both weight-stage depths,
+  including partial column tiles (192, 102) and several samples per tile."""
   rng = np.random.RandomState(2)
-  nB, L, Ci, Co, k = 2, 1024, 64, 64, 24
   x = H.int_tensor(rng, (nB, L, Ci))
   W = H.int_tensor(rng, (k, Ci, Co), -2, 2, 0.5)
-  ref = O.conv1d_same(x, W, None, 2)
-  op = H.pack(W.to(H.DEV), [(0, 1, Ci * Co, Co, 1)], Ci, Co, Ci, 64, k)
-  y = torch.zeros(nB, L // 2, Co, dtype=torch.float32, device=H.DEV)
-  d = H.conv_desc(H.to_pitch(x, Ci), op.buf, y, nB, L, Ci, k, 2, -11, L // 2,
-                  Co, L // 2, Co, 64, out_f32=True)
-  d.small_tile = small
-  H.run_conv(d)
+  b = H.int_tensor(rng, (Co,), -4, 4)
+  nseg = (nB + seg - 1) // seg
+  shifts = rng.randint(-2, 3, size=nseg).astype(np.int32)
+  ref = O.leaky_relu(
+      O.conv1d_same(_shuffle_batch(x, shifts, seg), W, b, 2)).to(BF16).float()
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  Lo = L // 2
+  pl = geo.same_padding_left(k, 2)
+  ck = nets._ck_for(cip, 2, k, Lo)
+  op = H.pack(W.to(H.DEV), [(0, 1, Ci * Co, Co, 1)], Ci, Co, cip, ck, k)
+  xd = H.to_pitch(x, cip)
+  y = torch.full((nB, Lo, cop), 7.0, dtype=BF16, device=H.DEV)
+  sh = torch.tensor(shifts, device=H.DEV)
+  bd = b.to(H.DEV)
+  d = H.conv_desc(xd, op.buf, y, nB, L, cip, k, 2, -pl, Lo, Co, Lo, cop, ck,
+                  bias=bd, shifts=sh, seg_size=seg, epilogue=_lib.EPI_LRELU)
+  _force_tile(d, tile, ks)
   H.sync()
-  np.testing.assert_array_equal(y.cpu().numpy(), ref.numpy())
+  got = y.float().cpu()
+  np.testing.assert_array_equal(got[:, :, :Co].numpy(), ref.numpy())
+  if cop > Co:
+    assert float(got[:, :, Co:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('tile,ks', ALL_TILES)
+@pytest.mark.parametrize('nB,L,Ci,Co,k', [(2, 512, 102, 128, 24),
+                                          (5, 128, 192, 256, 24)])
+def test_conv_dgrad_every_tile(tile, ks, nB, L, Ci, Co, k):
+  """Two-phase transposed convolution (f32 out, strided rows) + the fused
+  per-sample sum of squares on every tile."""
+  rng = np.random.RandomState(3)
+  W = H.int_tensor(rng, (k, Ci, Co), -1, 1, 0.5)
+  dy = H.int_tensor(rng, (nB, L // 2, Co), -2, 2)
+  x = torch.zeros(nB, L, Ci, requires_grad=True)
+  (O.conv1d_same(x, W, None, 2) * dy).sum().backward()
+  ref = x.grad
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  pl = geo.same_padding_left(k, 2)
+  phases = nets._transpose_phases(k, pl)
+  ck = nets._ck_for(cop, 1, k // 2, L // 2)
+  op = H.pack(W.to(H.DEV), [(t0, -2, Ci * Co, 1, Co) for t0, _ in phases], Co,
+              Ci, cop, ck, k // 2)
+  y = torch.full((nB, L, cip), 3.0, dtype=torch.float32, device=H.DEV)
+  offs = [o for _, o in phases]
+  dyd = H.to_pitch(dy, cop)
+  d = H.conv_desc(dyd, op.buf, y, nB, L // 2, cop, k // 2, 1, offs[0], L // 2,
+                  Ci, L, cip, ck, y_stride=2, y_off=0, out_f32=True, nphase=2,
+                  w_phase_stride=op.elems, off_phase_step=offs[1] - offs[0],
+                  yoff_phase_step=1)
+  rows, _, _ = _lib.TILES[tile]
+  ssq = None
+  if L // 2 >= rows:  # one sample per tile: the sum of squares can be fused
+    ssq = torch.zeros(nB, dtype=torch.float32, device=H.DEV)
+    d.rowsumsq = ssq.data_ptr()
+  _force_tile(d, tile, ks)
+  H.sync()
+  got = y.cpu()
+  np.testing.assert_array_equal(got[:, :, :Ci].numpy(), ref.numpy())
+  if cip > Ci:
+    assert float(got[:, :, Ci:].abs().max()) == 0.0
+  if ssq is not None:
+    np.testing.assert_allclose(ssq.cpu().numpy(),
+                               (ref**2).sum(dim=(1, 2)).numpy(), rtol=1e-5)
 
 
 DGRAD_CASES = [

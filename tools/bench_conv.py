@@ -63,13 +63,13 @@ def main():
                         nphase=nphase, w_phase_stride=op.elems,
                         off_phase_step=1, yoff_phase_step=1)
     if small >= 0:
-      d.small_tile = small
+      d.tile = small
     d.stage_ksteps = ksteps
     st = nets._stream()
     t = timeit(lambda: _lib.call('cg_swconv', ctypes.byref(d), st))
     fl = 2.0 * nB * Lu * N * taps * Cx * nphase
     print('conv R%d taps%d nB%d Lu%d Cx%d N%d CK%d small%d ks%d: %.1f us  %.1f TF/s'
-          % (R, taps, nB, Lu, Cx, N, CK, d.small_tile, ksteps, t * 1e6,
+          % (R, taps, nB, Lu, Cx, N, CK, d.tile, ksteps, t * 1e6,
              fl / t / 1e12))
   else:
     R, taps, nB, Lx, Cx, Cg = a[:6]

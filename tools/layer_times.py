@@ -52,7 +52,7 @@ def main():
     ms = s.elapsed_time(e)
     if fam == 'swconv':
       key = ('swconv', d.stride, d.taps, d.nB, d.Lu, d.Cx, d.N, d.CK, d.nphase,
-             d.small_tile, d.epilogue)
+             d.tile, d.epilogue)
       flops = 2.0 * d.nB * d.Lu * d.N * d.taps * d.Cx * d.nphase
     else:
       key = ('wgrad', d.stride, d.taps, d.nB, d.Lu, d.Cx, d.Cg, 0, 0, 0, 0)
