@@ -29,10 +29,14 @@ from ... import nets
 from .gan import GAN
 from .registry import register
 
-# hipGraph capture of train(): the ~370 launches of one step replay as
-# n_critic + 2 graphs cut at the gradient all-reduces (the RCCL calls stay
-# eager between replays), removing launch gaps.  CALCIUMGAN_GRAPH=0 disables it.
+# hipGraph capture of train(): the ~370 launches of one step replay as ONE
+# graph on a single rank, and under data parallelism as 2 * n_critic + 3 graphs
+# cut around the gradient all-reduces (the RCCL calls stay eager between
+# replays and overlap the graphs that do not need their result), removing
+# launch gaps.  CALCIUMGAN_GRAPH=0 disables it.
 _GRAPH_WARMUP_CALLS = 2
+# development knob: keep the multi-rank segmentation on a single rank
+_FORCE_SPLIT = os.environ.get('CALCIUMGAN_SPLIT_SEGMENTS', '0') == '1'
 
 
 @register('wgan-gp')
@@ -79,15 +83,17 @@ class WGAN_GP(GAN):
     return -fake_output.mean()
 
   def _critic_forward(self, st, real, z, alpha, shifts, slot,
-                      real_cached=False):
-    """Steps 1-5 of the critic schedule; leaves g in st['critic'].gin."""
+                      real_cached=False, fake=None):
+    """Steps 1-5 of the critic schedule; leaves g in st['critic'].gin.  `fake`
+    is G(z) when the generator forward already ran (_critic_generate)."""
     net_d = self.discriminator.net
     B = real.shape[0]
     lay = net_d.layers[0]
     plan = st['critic']
     s = nets._stream()
     plan.shifts.copy_(shifts, non_blocking=True)
-    fake = st['gws'].forward(z)
+    if fake is None:
+      fake = st['gws'].forward(z)
     _lib.call('cg_interp_pack', nets._p(real), nets._p(fake), nets._p(alpha),
               nets._p(st['dws'].act[0]), B, lay.lin, lay.cin, lay.cin, lay.cinp,
               lay.cinp, 0 if real_cached else 1, s)
@@ -110,30 +116,43 @@ class WGAN_GP(GAN):
     return fake
 
   # -- the step, cut at the all-reduce points ---------------------------------
-  def _critic_compute(self, real, r=None, slot=0, real_cached=False):
+  def _critic_generate(self, real, r=None):
+    """fake = G(z) of one critic update (wgan_gp.py:65-67).  It reads no
+    discriminator state, so train() runs it while the previous update's
+    gradient all-reduce is still in flight."""
+    B = real.shape[0]
+    st = self._get_state(B)
+    if r is None or 'shifts_dev' in r:
+      z = self.get_noise(B)
+    else:
+      z = self._to_device(r['z'])
+    return st['gws'].forward(z)
+
+  def _critic_compute(self, real, r=None, slot=0, real_cached=False,
+                      fake=None):
     """wgan_gp.py:64-80 up to (not including) the optimizer update: leaves the
     critic gradients in discriminator.net.params.grad."""
     B = real.shape[0]
     st = self._get_state(B)
     net_d = self.discriminator.net
     lay = net_d.layers[0]
+    if fake is None:
+      fake = self._critic_generate(real, r)
     if r is None:
-      z = self.get_noise(B)
       alpha = self._streams.alpha(B)
       shifts = self._streams.shifts(3)
     elif 'shifts_dev' in r:  # graph replay: draws staged in device memory
-      z = self.get_noise(B)
       alpha = self._streams.alpha(B)
       shifts = r['shifts_dev']
     else:
-      z = self._to_device(r['z'])
       alpha = self._to_device(r['alpha'])
       shifts = torch.stack([
           torch.as_tensor(r['shifts_real'], dtype=torch.int32),
           torch.as_tensor(r['shifts_fake'], dtype=torch.int32),
           torch.as_tensor(r['shifts_inter'], dtype=torch.int32)
       ], dim=1)
-    self._critic_forward(st, real, z, alpha, shifts, slot, real_cached)
+    self._critic_forward(st, real, None, alpha, shifts, slot, real_cached,
+                         fake=fake)
     plan = st['critic']
     s = nets._stream()
     n = lay.lin * lay.cinp
@@ -159,25 +178,23 @@ class WGAN_GP(GAN):
     self._critic_apply(lr_t_dev)
     return st['loss'][slot, 0], st['gp'][slot]
 
-  def _gen_compute(self, real, r=None):
+  def _gen_compute(self, real, r=None, fake=None):
     """wgan_gp.py:22-36 up to the optimizer update."""
     B = real.shape[0]
     st = self._get_state(B)
     net_g, net_d = self.generator.net, self.discriminator.net
     lay = net_d.layers[0]
     plan = st['gen']
+    if fake is None:
+      fake = self._critic_generate(real, r)  # same op: fake = G(z)
     if r is None:
-      z = self.get_noise(B)
       shifts = self._streams.shifts(1)
     elif 'shifts_dev' in r:
-      z = self.get_noise(B)
       shifts = r['shifts_dev']
     else:
-      z = self._to_device(r['z'])
       shifts = torch.as_tensor(r['shifts'], dtype=torch.int32).reshape(4, 1)
     s = nets._stream()
     plan.shifts.copy_(shifts, non_blocking=True)
-    fake = st['gws'].forward(z)
     _lib.call('cg_cast_pad', nets._p(fake), nets._p(st['dws'].act[0]),
               B * lay.lin, lay.cin, lay.cinp, lay.cinp, s)
     plan.forward()
@@ -187,11 +204,15 @@ class WGAN_GP(GAN):
     net_g.params.grad.zero_()
     st['gws'].backward(plan.gin)
 
-  def _gen_apply(self, real, lr_t_dev=None):
+  def _gen_metrics(self, real):
+    """gan.py:32-41 on the fake batch of the generator update."""
     st = self._get_state(real.shape[0])
+    return self.metrics(real, st['gws'].fake, fake_pitch=self.generator.net.Cp)
+
+  def _gen_apply(self, real, lr_t_dev=None, metrics=None):
     self.gen_optimizer.update(self.generator, self._sync.grad_scale,
                               lr_t_dev=lr_t_dev)
-    return self.metrics(real, st['gws'].fake, fake_pitch=self.generator.net.Cp)
+    return self._gen_metrics(real) if metrics is None else metrics
 
   def _train_generator(self, inputs, r=None, lr_t_dev=None):
     """wgan_gp.py:22-36."""
@@ -203,56 +224,99 @@ class WGAN_GP(GAN):
     return st['gen_loss'][0], metrics
 
   def _segments(self, real, rand=None, lr_dev=None, out=None):
-    """One train() (wgan_gp.py:82-95) as n_critic + 2 launch segments cut at
-    the gradient all-reduces: segment i ends with the gradients of update i
-    complete; the all-reduce of (flat_grad) follows it.  Returns
-    [(callable, flat_grad_to_reduce_or_None)]; the last callable stores the
-    step's outputs in out['value']."""
+    """One train() (wgan_gp.py:82-95) as launch segments cut around the
+    gradient all-reduces.  Returns [(callable, flat_grad_or_None, wait)]:
+    after a segment with a gradient buffer its all-reduce is STARTED; a segment
+    with wait=True needs the pending all-reduce finished first.  Work that
+    does not read the reduced gradients -- the next update's G(z), the signal
+    metrics -- sits in wait=False segments and overlaps the collective:
+
+      [G(z0) D-step0] ar | [G(z1)] wait [adam0 D-step1] ar | ... |
+      [G(zg)] wait [adam D fwd/bwd, G bwd] ar | [metrics] wait [adam_G, outputs]
+
+    The last callable stores the step's outputs in out['value']."""
     n = self.n_critic
     st = self._get_state(real.shape[0])
     out = {} if out is None else out
     lr = (lambda i: None) if lr_dev is None else (lambda i: lr_dev[i:])
     rc = (lambda i: None) if rand is None else (lambda i: rand['critic'][i])
+    rg = None if rand is None else rand['gen']
     d_grad = self.discriminator.net.params.grad
     g_grad = self.generator.net.params.grad
+    box = {}
 
-    def critic_seg(i):
+    def generate(key, r):
+      def run():
+        box[key] = self._critic_generate(real, r)
+      return run
+
+    def critic_seg(i, own_g):
       def run():
         if i > 0:
           self._critic_apply(lr(i - 1))
         # the bf16 copy of `real` in X0[0:B] survives a critic step (only the
         # x^ segment is overwritten): converted once per train()
-        self._critic_compute(real, rc(i), slot=i, real_cached=i > 0)
+        self._critic_compute(real, rc(i), slot=i, real_cached=i > 0,
+                             fake=None if own_g else box.pop(i))
       return run
 
     def gen_seg():
       if n > 0:
         self._critic_apply(lr(n - 1))
-      self._gen_compute(real, None if rand is None else rand['gen'])
+      self._gen_compute(real, rg, fake=box.pop('g'))
+
+    def metrics_seg():
+      box['metrics'] = self._gen_metrics(real)
 
     def last_seg():
-      metrics = self._gen_apply(real, lr(n))
+      metrics = self._gen_apply(real, lr(n), metrics=box.pop('metrics'))
       dis_loss = st['loss'][:n, 0].mean()
       gradient_penalty = st['gp'][:n].mean()
       out['value'] = (st['gen_loss'][0].clone(), dis_loss, gradient_penalty,
                       metrics)
 
-    segs = [(critic_seg(i), d_grad) for i in range(n)]
-    segs.append((gen_seg, g_grad))
-    segs.append((last_seg, None))
+    segs = []
+    for i in range(n):
+      if i == 0:
+        segs.append((critic_seg(0, True), d_grad, False))
+      else:
+        segs.append((generate(i, rc(i)), None, False))
+        segs.append((critic_seg(i, False), d_grad, True))
+    segs.append((generate('g', rg), None, False))
+    segs.append((gen_seg, g_grad, True))
+    segs.append((metrics_seg, None, False))
+    segs.append((last_seg, None, True))
+    if self._sync.world == 1 and not _FORCE_SPLIT:
+      # no collective to cut around: the whole step is one segment (one graph)
+      fns = [fn for fn, _, _ in segs]
+
+      def run_all():
+        for fn in fns:
+          fn()
+      segs = [(run_all, None, False)]
     return segs, out
+
+  def _run_segments(self, segs, launch):
+    """Drive (callable, grad, wait) segments; `launch` runs one callable."""
+    pending = None
+    for fn, grad, wait in segs:
+      if wait and pending is not None:
+        pending.wait()
+        pending = None
+      launch(fn)
+      if grad is not None:
+        pending = self._sync.all_reduce_async(grad)
+    if pending is not None:
+      pending.wait()
 
   def _train_body(self, real, rand=None):
     segs, out = self._segments(real, rand)
-    for fn, grad in segs:
-      fn()
-      if grad is not None:
-        self._sync.all_reduce(grad)
+    self._run_segments(segs, lambda fn: fn())
     return out['value']
 
   def _capture(self, real, st):
     """Capture one train() as hipGraphs, one per segment (RCCL all-reduces stay
-    eager between replays).  Host-drawn inputs of a replay (phase shifts, Adam
+    eager between replays, overlapped with the wait=False segments).  Host-drawn inputs of a replay (phase shifts, Adam
     step sizes) travel through pinned staging buffers that the first graph
     copies to the device; z / alpha come from the graph-registered device
     generator."""
@@ -274,7 +338,7 @@ class WGAN_GP(GAN):
     graphs = []
     pool = None
     torch.cuda.synchronize()
-    for k, (fn, grad) in enumerate(segs):
+    for k, (fn, grad, wait) in enumerate(segs):
       graph = torch.cuda.CUDAGraph()
       graph.register_generator_state(self._streams.local)
       with torch.cuda.graph(graph, pool=pool):
@@ -283,7 +347,7 @@ class WGAN_GP(GAN):
           g['lr_dev'].copy_(g['lr_host'], non_blocking=True)
         fn()
       pool = graph.pool()
-      graphs.append((graph, grad))
+      graphs.append((graph.replay, grad, wait))
     # capture only records: undo the host-side step counters it advanced
     self.dis_optimizer.iterations, self.gen_optimizer.iterations = it_d, it_g
     g['graphs'] = graphs
@@ -305,10 +369,7 @@ class WGAN_GP(GAN):
       g['lr_host'][i] = self.dis_optimizer.lr_t(self.dis_optimizer.iterations +
                                                 i + 1)
     g['lr_host'][n] = self.gen_optimizer.lr_t(self.gen_optimizer.iterations + 1)
-    for graph, grad in g['graphs']:
-      graph.replay()
-      if grad is not None:
-        self._sync.all_reduce(grad)
+    self._run_segments(g['graphs'], lambda replay: replay())
     self.dis_optimizer.iterations += n
     self.gen_optimizer.iterations += 1
     return g['out']

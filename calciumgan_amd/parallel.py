@@ -60,6 +60,14 @@ class GradSync(object):
       dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
 
+  def all_reduce_async(self, flat_grad):
+    """Start the sum-all-reduce and return its work handle (None for one
+    rank): `handle.wait()` orders the current stream after the collective, so
+    launches issued in between overlap it."""
+    if self.world > 1:
+      return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
   def mean_scalars(self, t):
     """Average a small tensor of logged scalars across ranks (in place)."""
     if self.world > 1:
