@@ -210,14 +210,41 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
 # static default for run-to-run bit reproducibility).
 _TILE_CACHE = {}
 _AUTOTUNE = __import__('os').environ.get('CALCIUMGAN_AUTOTUNE', '1') != '0'
+# CALCIUMGAN_TILE_CACHE=<file.json>: choices are loaded from / saved to this
+# file, so later processes (profiler passes, the other ranks' restarts) launch
+# exactly the tuned configuration without re-timing candidates.
+_TILE_CACHE_FILE = __import__('os').environ.get('CALCIUMGAN_TILE_CACHE')
+
+
+def _load_tile_cache():
+  import json
+  import os
+  if _TILE_CACHE_FILE and os.path.exists(_TILE_CACHE_FILE):
+    with open(_TILE_CACHE_FILE) as f:
+      for k, v in json.load(f).items():
+        _TILE_CACHE[tuple(int(t) for t in k.split(','))] = tuple(v)
+
+
+def _save_tile_cache():
+  import json
+  if _TILE_CACHE_FILE and _TILE_CACHE:
+    with open(_TILE_CACHE_FILE, 'w') as f:
+      json.dump({','.join(str(t) for t in k): list(v)
+                 for k, v in _TILE_CACHE.items()}, f, indent=0)
+
+
+_load_tile_cache()
+__import__('atexit').register(_save_tile_cache)
 
 
 def _autotune_tile(d):
-  if not _AUTOTUNE or not torch.cuda.is_available():
+  if not torch.cuda.is_available():
     return
   key = (d.stride, d.taps, d.nB, d.Lx, d.Cx, d.Lu, d.N, d.CK, d.nphase,
          d.epilogue, d.out_f32)
   best = _TILE_CACHE.get(key)
+  if best is None and not _AUTOTUNE:
+    return
   if best is None:
     lib = _lib.load()
     st = _stream()

@@ -25,6 +25,10 @@ CONFIGS = {
     'tiny_noln': (64, 6, 8, 24, 2, 4, False),
     'mid': (256, 16, 32, 24, 2, 6, True),  # BASELINE cfg1 shapes, small batch
     'odd_c': (128, 102, 16, 24, 3, 3, True),
+    'b1': (64, 6, 8, 24, 2, 1, True),          # single-sample batch
+    'm0_k8': (128, 6, 8, 8, 0, 3, True),       # no phase shuffle, 8-tap kernels
+    'long': (2048, 6, 8, 24, 10, 2, True),     # cfg2 length / shifts: 256-row
+                                               # tiles, fused penalty norm
 }
 
 

@@ -2,6 +2,9 @@
 # for FETCH_SIZE and WRITE_SIZE: they do not fit one pass on gfx950).
 export TMPDIR=/tmp
 export CALCIUMGAN_GRAPH=0
+# tune once (no profiler), then profile exactly the tuned launches
+export CALCIUMGAN_TILE_CACHE=/tmp/cg_tiles.json
+python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_kernel_timing > gpurun_out/traffic_tune.log 2>&1
 export CALCIUMGAN_AUTOTUNE=0
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/traffic_$c -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_kernel_timing > gpurun_out/traffic_$c.log 2>&1
