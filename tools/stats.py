@@ -1,11 +1,19 @@
-"""Condense a rocprofv3 --stats kernel_stats.csv into per-step milliseconds."""
+"""Condense a rocprofv3 --stats kernel_stats.csv into per-step milliseconds,
+with the two MFMA kernel families aggregated over their instantiations (the
+numbers bench.py's `roofline` object must agree with)."""
 import csv, glob, re, sys
 d, steps = sys.argv[1], float(sys.argv[2])
 f = glob.glob(d + "/*/*kernel_stats.csv")[0] if not d.endswith('.csv') else d
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("launch set: %s  (divided by %g recorded train() steps incl. warm-up/timing passes)" % (f.split('/')[-1], steps))
+print("launch set: %s  (divided by %g recorded train() steps: warm-up + timed + the eager instrumented pass)" % (f.split('/')[-1], steps))
 print("total kernel ms/step %.2f" % (tot / 1e6 / steps))
+for fam in ("swconv_kernel", "wgrad_kernel"):
+    sel = [r for r in rows if fam in r["Name"]]
+    calls = sum(int(r["Calls"]) for r in sel)
+    ns = sum(float(r["TotalDurationNs"]) for r in sel)
+    print("FAMILY %-14s %6d calls (%.1f per step) %8.1f us avg %6.2f ms/step %5.1f%%" % (
+        fam, calls, calls / steps, ns / calls / 1e3, ns / 1e6 / steps, 100 * ns / tot))
 for r in rows[:34]:
     n = r["Name"]
     m = re.search(r"(\w+_kernel(<[^>]*>)?)", n)
