@@ -320,20 +320,28 @@ swconv_kernel(ConvArgs a) {
     }
   }
 
-  // ---- epilogue: accumulators -> LDS -> row-contiguous 16-byte stores ----
+  // ---- epilogue: accumulators -> LDS -> whole-line row-contiguous stores ----
   __syncthreads();
   float* scr = reinterpret_cast<float*>(smem) + wave * (16 * kScrPitch);
-  const int erow = lane >> 2;
-  const int ecol = (lane & 3) * 16;
+  // Read-back map: 8 rows per pass, 8 lanes per row, 8 output channels per lane
+  // as two groups of four, placed so that EVERY store instruction writes whole
+  // 128-byte runs per row (full sectors; 16-byte pieces at a 32/64-byte stride
+  // would leave the L2 to merge half-written sectors):
+  //   bf16 out: columns cg*8 + {0..3 | 4..7}      -> one 16-byte store
+  //   f32  out: columns cg*4 + {0..3} | 32 + same -> two 16-byte stores
+  const int erow = lane >> 3;
+  const int cg8 = lane & 7;
+  const int colA = a.out_f32 ? cg8 * 4 : cg8 * 8;
+  const int colB = a.out_f32 ? colA + 32 : colA + 4;
+  const int nA = n0 + wn * 64 + colA;
+  const int nB = n0 + wn * 64 + colB;
   float ssq = 0.f;  // sum of squares of this lane's outputs (rowsumsq)
-  float bv[2][8];  // this lane's 16 output channels' bias (0 when absent/pad)
+  float bv[8];      // this lane's 8 output channels' bias (0 when absent/pad)
 #pragma unroll
-  for (int half = 0; half < 2; ++half)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int n = n0 + wn * 64 + ecol + 8 * half + e;
-      bv[half][e] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
-    }
+  for (int e = 0; e < 4; ++e) {
+    bv[e] = (a.bias && nA + e < a.N) ? a.bias[nA + e] : 0.f;
+    bv[4 + e] = (a.bias && nB + e < a.N) ? a.bias[nB + e] : 0.f;
+  }
   // 16 rows x 64 columns of the wave tile at a time
 #pragma unroll
   for (int mh = 0; mh < MT * KH; ++mh) {
@@ -358,61 +366,60 @@ swconv_kernel(ConvArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int i = (wm * MT + mt) * MF + h * 16 + erow;
-    const int m = m0 + i;
-    if (m < a.M) {
-      const int b = m / a.Lu;
-      const int u = m - b * a.Lu;
-      const long long rowoff =
-          ((long long)b * a.Ly + (long long)a.y_stride * u + y_off) * a.Cy;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int n = n0 + wn * 64 + ecol + 8 * half;
-        if (n < a.Cy) {
-          float v[8];
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(
-              scr + erow * kScrPitch + ecol + 8 * half);
-          const f32x4 v1 = *reinterpret_cast<const f32x4*>(
-              scr + erow * kScrPitch + ecol + 8 * half + 4);
-          v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
-          v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
-          const int nval = a.N - n;  // valid channels in this 8-group
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = pass * 8 + erow;
+      const int m = m0 + (wm * MT + mt) * MF + h * 16 + row;
+      if (m < a.M && nA < a.Cy) {
+        const int b = m / a.Lu;
+        const int u = m - b * a.Lu;
+        const long long rowoff =
+            ((long long)b * a.Ly + (long long)a.y_stride * u + y_off) * a.Cy;
+        const f32x4 v0 =
+            *reinterpret_cast<const f32x4*>(scr + row * kScrPitch + colA);
+        const f32x4 v1 =
+            *reinterpret_cast<const f32x4*>(scr + row * kScrPitch + colB);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const bool okB = nB < a.Cy;  // f32 out: second half past the pitch
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bv[half][e];
-          if (a.epilogue == CG_EPI_LRELU) {
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        if (a.epilogue == CG_EPI_LRELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], a.alpha * v[e]);
-          } else if (a.epilogue == CG_EPI_MASK) {
-            const uint4 hm = *reinterpret_cast<const uint4*>(a.mask + rowoff + n);
-            const uint32_t hw[4] = {hm.x, hm.y, hm.z, hm.w};
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], a.alpha * v[e]);
+        } else if (a.epilogue == CG_EPI_MASK) {
+          const uint2 ha = *reinterpret_cast<const uint2*>(a.mask + rowoff + nA);
+          const uint2 hb = okB ? *reinterpret_cast<const uint2*>(a.mask + rowoff + nB)
+                               : make_uint2(0u, 0u);
+          const uint32_t hw[4] = {ha.x, ha.y, hb.x, hb.y};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const uint16_t hb = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
-              v[e] *= (bf2f(hb) > 0.f) ? 1.f : a.alpha;
-            }
-          } else if (a.epilogue == CG_EPI_SIGMOID) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+          for (int e = 0; e < 8; ++e) {
+            const uint16_t hv = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
+            v[e] *= (bf2f(hv) > 0.f) ? 1.f : a.alpha;
           }
-          if (nval < 8) {  // channel padding stays exactly zero
+        } else if (a.epilogue == CG_EPI_SIGMOID) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (e >= nval) v[e] = 0.f;
-          }
-          if (a.rowsumsq) {
+          for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+        }
+        // channel padding [N, Cy) stays exactly zero
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
-          }
-          if (a.out_f32) {
-            float* dst = reinterpret_cast<float*>(a.y) + rowoff + n;
-            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-          } else {
-            uint16_t* dst = reinterpret_cast<uint16_t*>(a.y) + rowoff + n;
-            *reinterpret_cast<uint4*>(dst) =
-                make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
-                           pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-          }
+        for (int e = 0; e < 4; ++e) {
+          if (nA + e >= a.N) v[e] = 0.f;
+          if (nB + e >= a.N) v[4 + e] = 0.f;
+        }
+        if (a.rowsumsq) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
+        }
+        if (a.out_f32) {
+          float* dst = reinterpret_cast<float*>(a.y) + rowoff;
+          *reinterpret_cast<f32x4*>(dst + nA) = f32x4{v[0], v[1], v[2], v[3]};
+          if (okB)
+            *reinterpret_cast<f32x4*>(dst + nB) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          uint16_t* dst = reinterpret_cast<uint16_t*>(a.y) + rowoff + nA;
+          *reinterpret_cast<uint4*>(dst) =
+              make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
+                         pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
         }
       }
     }
