@@ -16,8 +16,7 @@ inline unsigned grid1d(long long work, int per_block, long long cap = 1 << 20) {
   return (unsigned)b;
 }
 
-__device__ __forceinline__ void load8(const uint16_t* p, float* v) {
-  const uint4 u = *reinterpret_cast<const uint4*>(p);
+__device__ __forceinline__ void unpack8(const uint4 u, float* v) {
   const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -25,10 +24,39 @@ __device__ __forceinline__ void load8(const uint16_t* p, float* v) {
     v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
   }
 }
+__device__ __forceinline__ uint4 ldg16(const uint16_t* p) {
+  return *reinterpret_cast<const uint4*>(p);
+}
+__device__ __forceinline__ void load8(const uint16_t* p, float* v) {
+  unpack8(ldg16(p), v);
+}
 __device__ __forceinline__ void store8(uint16_t* p, const float* v) {
   *reinterpret_cast<uint4*>(p) =
       make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]),
                  pack2bf(v[6], v[7]));
+}
+
+// 8 consecutive f32 channels of a row whose pitch is `pitch` floats, with the
+// widest aligned loads the pitch allows (16 / 8 / 4 bytes); channels at or past
+// `nvalid` read as zero.
+__device__ __forceinline__ void load8f(const float* p, int nvalid, int pitch,
+                                       float* v) {
+  if (nvalid >= 8 && (pitch & 3) == 0) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a0[0]; v[1] = a0[1]; v[2] = a0[2]; v[3] = a0[3];
+    v[4] = a1[0]; v[5] = a1[1]; v[6] = a1[2]; v[7] = a1[3];
+  } else if (nvalid >= 8 && (pitch & 1) == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float2 t = *reinterpret_cast<const float2*>(p + 2 * e);
+      v[2 * e] = t.x;
+      v[2 * e + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = e < nvalid ? p[e] : 0.f;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -65,13 +93,23 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(
   }
   const float invC = 1.f / C;
   const long long row0 = wave_id * (long long)rpw * rows_per_slot + slot;
-  for (int it = 0; it < rows_per_slot; ++it) {
-    const long long row = row0 + (long long)it * rpw;
+  // kRB rows' loads are issued before any of them is reduced: one 16-byte load
+  // per lane in flight cannot cover the HBM latency at this occupancy
+  constexpr int kRB = 4;
+  for (int it0 = 0; it0 < rows_per_slot; it0 += kRB) {
+   uint4 raw[kRB];
+#pragma unroll
+   for (int k = 0; k < kRB; ++k) {
+     const long long row = row0 + (long long)(it0 + k) * rpw;
+     raw[k] = (row < rows && active) ? ldg16(y + row * Cp + c0)
+                                     : make_uint4(0u, 0u, 0u, 0u);
+   }
+#pragma unroll
+   for (int k = 0; k < kRB; ++k) {
+    const long long row = row0 + (long long)(it0 + k) * rpw;
     const bool rv = row < rows;  // uniform inside the LPR group
     float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    if (rv && active) load8(y + row * Cp + c0, v);
+    unpack8(raw[k], v);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -102,6 +140,7 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(
       }
       store8(h + row * Cp + c0, o);
     }
+   }
   }
 }
 
@@ -142,22 +181,30 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
   }
   const float invC = 1.f / C;
   const long long row0 = wave_id * (long long)rpw * rows_per_slot + slot;
-  for (int it = 0; it < rows_per_slot; ++it) {
-    const long long row = row0 + (long long)it * rpw;
+  constexpr int kRB = 2;  // rows whose loads are in flight together
+  for (int it0 = 0; it0 < rows_per_slot; it0 += kRB) {
+   uint4 rd[kRB], rh[kRB], ry[kRB];
+   float rmean[kRB], rrstd[kRB];
+#pragma unroll
+   for (int k = 0; k < kRB; ++k) {
+     const long long row = row0 + (long long)(it0 + k) * rpw;
+     const bool ok = row < rows;
+     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+     rmean[k] = ok ? mean_i[row] : 0.f;
+     rrstd[k] = ok ? rstd_i[row] : 0.f;
+     rd[k] = (ok && active) ? ldg16(dh + row * Cp + c0) : z;
+     rh[k] = (ok && active) ? ldg16(h + row * Cp + c0) : z;
+     ry[k] = (ok && active) ? ldg16(y + row * Cp + c0) : z;
+   }
+#pragma unroll
+   for (int k = 0; k < kRB; ++k) {
+    const long long row = row0 + (long long)(it0 + k) * rpw;
     const bool rv = row < rows;
     float vd[8], vh[8], vy[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) vd[e] = vh[e] = vy[e] = 0.f;
-    float mean = 0.f, rstd = 0.f;
-    if (rv) {
-      mean = mean_i[row];
-      rstd = rstd_i[row];
-      if (active) {
-        load8(dh + row * Cp + c0, vd);
-        load8(h + row * Cp + c0, vh);
-        load8(y + row * Cp + c0, vy);
-      }
-    }
+    unpack8(rd[k], vd);
+    unpack8(rh[k], vh);
+    unpack8(ry[k], vy);
+    const float mean = rmean[k], rstd = rrstd[k];
     float xh[8], dyh[8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -185,6 +232,7 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
       }
       store8(dy + row * Cp + c0, o);
     }
+   }
   }
   if (active) {
 #pragma unroll
@@ -213,14 +261,27 @@ __global__ __launch_bounds__(kThreads) void dense1_fwd_kernel(
   __shared__ float part[4];
   const int b = blockIdx.x;
   float s = 0.f;
-  for (int i = threadIdx.x * 8; i < F; i += kThreads * 8) {
-    float v[8];
-    load8(h + (long long)b * F + i, v);
-    const int t = i / Cp;
-    const int c = i - t * Cp;
+  constexpr int kNB = 4;  // 16-byte loads in flight per lane
+  for (int i0 = threadIdx.x * 8; i0 < F; i0 += kNB * kThreads * 8) {
+    uint4 raw[kNB];
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (c + e < C) s += v[e] * bf2f(f2bf(w[t * C + c + e]));
+    for (int k = 0; k < kNB; ++k) {
+      const int i = i0 + k * kThreads * 8;
+      raw[k] = i < F ? ldg16(h + (long long)b * F + i)
+                     : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) {
+      const int i = i0 + k * kThreads * 8;
+      if (i >= F) break;
+      float v[8];
+      unpack8(raw[k], v);
+      const int t = i / Cp;
+      const int c = i - t * Cp;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (c + e < C) s += v[e] * bf2f(f2bf(w[t * C + c + e]));
+    }
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
@@ -258,14 +319,25 @@ __global__ __launch_bounds__(kThreads) void dense1_wgrad_kernel(
   const int i = (blockIdx.x * kThreads + threadIdx.x) * 8;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float bsum = 0.f;
-  for (int b = blockIdx.y; b < nB; b += gridDim.y) {
-    const float c = coef[b / seg_size];
-    if (i == 0 && bias_coef) bsum += bias_coef[b / seg_size];
-    if (i < F) {
-      float v[8];
-      load8(x + (long long)b * F + i, v);
+  constexpr int kNB = 4;  // samples whose loads are in flight together
+  for (int b0 = blockIdx.y; b0 < nB; b0 += kNB * gridDim.y) {
+    uint4 raw[kNB];
+    float cf[kNB];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += c * v[e];
+    for (int k = 0; k < kNB; ++k) {
+      const int b = b0 + k * gridDim.y;
+      const bool ok = b < nB;
+      cf[k] = ok ? coef[b / seg_size] : 0.f;
+      if (ok && i == 0 && bias_coef) bsum += bias_coef[b / seg_size];
+      raw[k] = (ok && i < F) ? ldg16(x + (long long)b * F + i)
+                             : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) {
+      float v[8];
+      unpack8(raw[k], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += cf[k] * v[e];
     }
   }
   if (i < F) {
@@ -340,13 +412,12 @@ __global__ __launch_bounds__(kThreads) void interp_pack_kernel(
   const int b = (int)(row / L);
   const float al = alpha[b];
   float r[8], f[8], x[8];
+  // (the 8-channel group base c is a multiple of 8, so the loads are aligned
+  // whenever the pitch is)
+  load8f(real + row * Cr + c, C - c, Cr, r);
+  load8f(fake + row * Cf + c, C - c, Cf, f);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const bool ok = c + e < C;
-    r[e] = ok ? real[row * Cr + c + e] : 0.f;
-    f[e] = ok ? fake[row * Cf + c + e] : 0.f;
-    x[e] = al * r[e] + (1.f - al) * f[e];
-  }
+  for (int e = 0; e < 8; ++e) x[e] = al * r[e] + (1.f - al) * f[e];
   const long long seg = (long long)B * L * Cp;
   if (write_real) store8(x0 + row * Cp + c, r);
   store8(x0 + seg + row * Cp + c, f);
@@ -542,49 +613,76 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(
   p[i] -= lr_t * mi / (sqrtf(vi) + eps);
 }
 
-// one wave per row (b,t): min/max/mean/std over channels of real and fake
+// min/max/mean/std over the channels of each (b,t) row of real and of fake,
+// squared differences summed into out[4].  A row is covered by LPR lanes of 8
+// channels (LPR = power of two >= C/8, <= 64), 64/LPR rows per wave at a time;
+// rows wider than 512 channels loop over 512-channel spans.
 __global__ __launch_bounds__(kThreads) void signal_metrics_kernel(
     const float* __restrict__ real, const float* __restrict__ fake,
     float* __restrict__ out, long long rows, int C, int Cr, int Cf, float smin,
-    float scale, int rows_per_wave) {
+    float scale, int lpr, int log2lpr, int rows_per_slot) {
   __shared__ float part[4][4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const int sub = lane & (lpr - 1);
+  const int slot = lane >> log2lpr;
+  const int rpw = 64 >> log2lpr;
   float acc[4] = {0, 0, 0, 0};
-  const long long r0 = ((long long)blockIdx.x * 4 + wave) * rows_per_wave;
-  for (int rr = 0; rr < rows_per_wave; ++rr) {
-    const long long row = r0 + rr;
-    if (row >= rows) break;
+  const long long wave_id = (long long)blockIdx.x * 4 + wave;
+  const long long row0 = wave_id * (long long)rpw * rows_per_slot + slot;
+  const float invC = 1.f / C;
+  for (int it = 0; it < rows_per_slot; ++it) {
+    const long long row = row0 + (long long)it * rpw;
+    const bool rv = row < rows;
     float st[2][4];
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
       const float* p = which ? fake + row * Cf : real + row * Cr;
+      const int pitch = which ? Cf : Cr;
       float mn = INFINITY, mx = -INFINITY, s = 0.f;
-      for (int c = lane; c < C; c += 64) {
-        const float v = p[c] * scale + smin;
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
-        s += v;
+      for (int c = sub * 8; c < C; c += lpr * 8) {
+        float v[8];
+        if (rv) load8f(p + c, C - c, pitch, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (rv && c + e < C) {
+            const float t = v[e] * scale + smin;
+            mn = fminf(mn, t);
+            mx = fmaxf(mx, t);
+            s += t;
+          }
       }
-      mn = wave_min(mn);
-      mx = wave_max(mx);
-      const float mean = wave_sum(s) / C;
+      for (int o = lpr >> 1; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      }
+      const float mean = group_sum(s, lpr) * invC;
       float s2 = 0.f;
-      for (int c = lane; c < C; c += 64) {
-        const float d = p[c] * scale + smin - mean;
-        s2 += d * d;
+      for (int c = sub * 8; c < C; c += lpr * 8) {
+        float v[8];
+        if (rv) load8f(p + c, C - c, pitch, v);  // L1/L2 hit (or registers)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (rv && c + e < C) {
+            const float d = v[e] * scale + smin - mean;
+            s2 += d * d;
+          }
       }
       st[which][0] = mn;
       st[which][1] = mx;
       st[which][2] = mean;
-      st[which][3] = sqrtf(wave_sum(s2) / C);
+      st[which][3] = sqrtf(group_sum(s2, lpr) * invC);
     }
+    if (rv && sub == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float d = st[0][k] - st[1][k];
-      acc[k] += d * d;
+      for (int k = 0; k < 4; ++k) {
+        const float d = st[0][k] - st[1][k];
+        acc[k] += d * d;
+      }
     }
   }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = wave_sum(acc[k]);
   if (lane == 0)
     for (int k = 0; k < 4; ++k) part[wave][k] = acc[k];
   __syncthreads();
@@ -801,10 +899,14 @@ extern "C" int cg_adam(float* p, const float* grad, float* m, float* v,
 extern "C" int cg_signal_metrics(const float* real, const float* fake,
                                  float* out, long long rows, int C, int Cr,
                                  int Cf, float smin, float smax, void* stream) {
-  const int rows_per_wave = 16;
+  if (rows < 1 || C < 1 || Cr < C || Cf < C) return CG_EINVAL;
+  int lpr = 1, l2 = 0;
+  while (lpr * 8 < C && lpr < 64) { lpr <<= 1; ++l2; }
+  const int rpw = 64 / lpr;
+  const int rows_per_slot = 4;
   hipLaunchKernelGGL(signal_metrics_kernel,
-                     dim3(grid1d(rows, 4 * rows_per_wave, 1LL << 31)),
+                     dim3(grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31)),
                      dim3(kThreads), 0, S_(stream), real, fake, out, rows, C,
-                     Cr, Cf, smin, smax - smin, rows_per_wave);
+                     Cr, Cf, smin, smax - smin, lpr, l2, rows_per_slot);
   CG_LAUNCH_CHECK();
 }
