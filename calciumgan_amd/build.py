@@ -56,12 +56,13 @@ def build(force=False, verbose=True):
 
 
 HOST_LIB = os.path.join(CSRC, 'libcalciumgan_host.so')
-HOST_SOURCES = ['oasis_ar1.c']
+HOST_SOURCES = ['oasis_ar1.c', 'crc32c.c']
 
 
 def build_host(force=False, verbose=True):
   """gcc build of the host-side C helpers (OASIS AR(1) deconvolution for the
-  post-hoc spike statistics; not part of the GPU hot path)."""
+  post-hoc spike statistics, CRC-32C for TFRecord framing; not part of the GPU
+  hot path)."""
   srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
   if (not force and os.path.exists(HOST_LIB) and
       all(os.path.getmtime(s) <= os.path.getmtime(HOST_LIB) for s in srcs)):

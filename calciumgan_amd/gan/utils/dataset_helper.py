@@ -1,9 +1,11 @@
 """Input pipeline for the hot path (gan/utils/dataset_helper.py:113-206).
 
-The reference reads TFRecords of raw-float32 `signal` / `spike` features;
-TensorFlow is not available here, so the dataset directory holds the same
-segments as ``train.npy`` / ``validation.npy`` dicts next to an ``info.pkl``
-with the reference's keys (dataset/generate_tfrecords.py:229-248).  Batches
+The reference reads TFRecords of raw-float32 `signal` / `spike` features.  A
+dataset directory here holds an ``info.pkl`` with the reference's keys
+(dataset/generate_tfrecords.py:229-248) next to EITHER the reference's
+``train-*.record`` / ``validation-*.record`` files (decoded by
+``tfrecord.py``, no TensorFlow) OR the same segments as ``train.npy`` /
+``validation.npy`` dicts (what dataset/generate_dg_dataset.py writes).  Batches
 are float32 (B, L, C) in [0, 1]; the last batch of an epoch may be short
 (no drop_remainder, dataset_helper.py:173)."""
 import os
@@ -97,10 +99,21 @@ def get_dataset(hparams, summary=None):
     print('input directory {} cannot be found'.format(hparams.input_dir))
     exit()
   get_dataset_info(hparams)
-  with open(os.path.join(hparams.input_dir, 'train.npy'), 'rb') as f:
-    train = pickle.load(f)
-  with open(os.path.join(hparams.input_dir, 'validation.npy'), 'rb') as f:
-    validation = pickle.load(f)
+  if os.path.exists(os.path.join(hparams.input_dir, 'train.npy')):
+    with open(os.path.join(hparams.input_dir, 'train.npy'), 'rb') as f:
+      train = pickle.load(f)
+    with open(os.path.join(hparams.input_dir, 'validation.npy'), 'rb') as f:
+      validation = pickle.load(f)
+  else:
+    # the reference's own layout: train-*.record / validation-*.record
+    # (dataset_helper.py:116-118,147-182), decoded and cached in memory
+    from . import tfrecord
+    train, validation = ({
+        'signals': sig, 'spikes': spk
+    } for sig, spk in (tfrecord.read_segments(
+        os.path.join(hparams.input_dir, mode + '-*.record'),
+        hparams.signal_shape, hparams.spike_shape)
+                       for mode in ('train', 'validation')))
   if hparams.save_generated:
     cache_validation_set(hparams, validation)
   train_ds = ArrayDataset(train['signals'], train['spikes'], hparams.batch_size,
@@ -112,20 +125,38 @@ def get_dataset(hparams, summary=None):
   return train_ds, validation_ds
 
 
-def write_dataset(output_dir, signals, spikes, info, validation_size):
+def write_dataset(output_dir, signals, spikes, info, validation_size,
+                  tfrecords=False, num_per_shard=0):
   """Counterpart of dataset/generate_tfrecords.py:186-252: shuffle, split
-  off `validation_size` segments, write train/validation arrays + info.pkl."""
+  off `validation_size` segments, write train/validation + info.pkl.  With
+  `tfrecords` the segments go into the reference's sharded
+  ``<mode>-NNN-of-MMM.record`` files (generate_tfrecords.py:141-183; shard
+  split as its `split()`), else into one pickled array dict per mode."""
   os.makedirs(output_dir, exist_ok=True)
   rng = np.random.RandomState(1234)  # generate_tfrecords.py:14
   idx = rng.permutation(len(signals))
   train_size = len(signals) - validation_size
   parts = {'train': idx[:train_size], 'validation': idx[train_size:]}
+  shards = {'train': 1, 'validation': 1}
   for name, ii in parts.items():
-    with open(os.path.join(output_dir, name + '.npy'), 'wb') as f:
-      pickle.dump({'signals': signals[ii], 'spikes': spikes[ii]}, f, protocol=4)
+    if tfrecords:
+      from . import tfrecord
+      n = 1 if num_per_shard <= 0 else ceil(len(ii) / num_per_shard)
+      shards[name] = n
+      k, m = divmod(len(ii), n)
+      for s in range(n):
+        part = ii[s * k + min(s, m):(s + 1) * k + min(s + 1, m)]
+        tfrecord.write_segments(
+            tfrecord.record_filename(output_dir, name, s, n), signals[part],
+            spikes[part])
+    else:
+      with open(os.path.join(output_dir, name + '.npy'), 'wb') as f:
+        pickle.dump({'signals': signals[ii], 'spikes': spikes[ii]}, f,
+                    protocol=4)
   full = dict(info)
   full.update(train_size=train_size, validation_size=validation_size,
-              num_train_shards=1, num_validation_shards=1,
+              num_train_shards=shards['train'],
+              num_validation_shards=shards['validation'],
               buffer_size=train_size)
   with open(os.path.join(output_dir, 'info.pkl'), 'wb') as f:
     pickle.dump(full, f)

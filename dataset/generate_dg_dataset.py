@@ -26,12 +26,18 @@ def main():
   p.add_argument('--validation_size', default=1000, type=int)
   p.add_argument('--stride', default=2, type=int)
   p.add_argument('--seed', default=1234, type=int)
+  p.add_argument('--tfrecords', action='store_true',
+                 help="write the reference's train-*/validation-*.record "
+                 'shards instead of array files')
+  p.add_argument('--num_per_shard', default=0, type=int,
+                 help='segments per TFRecord shard (0: one shard per mode)')
   a = p.parse_args()
   d = dg.make_dataset(a.num_neurons, a.sequence_length, a.num_segments, a.seed,
                       a.stride)
   info = {k: v for k, v in d['info'].items() if k != 'rates_hz'}
   full = dataset_helper.write_dataset(a.output_dir, d['signals'], d['spikes'],
-                                      info, a.validation_size)
+                                      info, a.validation_size, a.tfrecords,
+                                      a.num_per_shard)
   print('saved {} train + {} validation segments of shape {} to {}'.format(
       full['train_size'], full['validation_size'], full['signal_shape'],
       a.output_dir))

@@ -147,3 +147,131 @@ def test_dataset_directory_roundtrip(tmp_path):
   assert sum(len(b[0]) for b in val_ds) == 6
   # validation cache for the spike-metric scripts (dataset_helper.py:12-30)
   assert h5_helper.get(hp.validation_cache, 'spikes').dtype == np.int8
+
+
+# ---------------------------------------------------------------------------
+# TFRecord layout of the reference's datasets (generate_tfrecords.py:128-153,
+# dataset_helper.py:147-182) without TensorFlow
+# ---------------------------------------------------------------------------
+def test_crc32c_known_answers_and_mask():
+  import struct
+  from calciumgan_amd.gan.utils import tfrecord as T
+  # RFC 3720 B.4 test vectors
+  assert T.crc32c(b'123456789') == 0xe3069283
+  assert T.crc32c(bytes(32)) == 0x8a9136aa
+  assert T.crc32c(bytes([0xff] * 32)) == 0x62a8ab43
+  assert T.crc32c(bytes(range(32))) == 0x46dd794e
+  assert T.crc32c(b'') == 0
+  # unaligned starts / tails take the byte-wise path
+  data = bytes(range(256)) * 5
+  whole = T.crc32c(data)
+  lib = T._host_lib()
+  for cut in (1, 3, 7, 8, 13, 1000):
+    c = lib.cg_crc32c(0, data[:cut], cut)
+    assert lib.cg_crc32c(c, data[cut:], len(data) - cut) == whole
+  # TFRecord mask: rotate right by 15, add the delta, mod 2^32
+  c = T.crc32c(struct.pack('<Q', 15))
+  assert T.masked_crc32c(struct.pack('<Q', 15)) == (
+      (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xffffffff)
+
+
+def test_example_wire_format_hand_assembled():
+  from calciumgan_amd.gan.utils import tfrecord as T
+  # Example{features{feature{key:"a" value{bytes_list{value:"xy"}}}}}, byte by
+  # byte from the protobuf encoding rules (tag = field << 3 | 2, then length)
+  expect = bytes([
+      0x0a, 0x0d,              # Example.features, 13 bytes
+      0x0a, 0x0b,              # Features.feature map entry, 11 bytes
+      0x0a, 0x01, ord('a'),    # entry.key
+      0x12, 0x06,              # entry.value (Feature), 6 bytes
+      0x0a, 0x04,              # Feature.bytes_list, 4 bytes
+      0x0a, 0x02, ord('x'), ord('y'),  # BytesList.value
+  ])
+  assert T.serialize_example({'a': b'xy'}) == expect
+  assert T.parse_example(expect) == {'a': b'xy'}
+  # unknown fields / other feature kinds are skipped, order is free
+  other = T._len_field(2, T._len_field(1, b'\x00\x00\x80\x3f'))  # float_list
+  entry_f = T._len_field(1, b'f') + T._len_field(2, other)
+  entry_s = T._len_field(1, b'signal') + T._len_field(
+      2, T._len_field(1, T._len_field(1, b'\x01\x02')))
+  ex = T._len_field(1, T._len_field(1, entry_f) + T._len_field(1, entry_s))
+  assert T.parse_example(ex) == {'signal': b'\x01\x02'}
+  # a payload longer than 127 bytes needs a two-byte varint length
+  big = T.serialize_example({'signal': bytes(300)})
+  assert T.parse_example(big)['signal'] == bytes(300)
+
+
+def test_tfrecord_directory_reads_like_the_array_directory(tmp_path):
+  import pytest
+  from calciumgan_amd.gan.utils import tfrecord as T
+  rng = np.random.RandomState(3)
+  L, C, n_train, n_val = 64, 6, 11, 4
+  sig = rng.rand(n_train + n_val, L, C).astype(np.float32)
+  spk = (rng.rand(n_train + n_val, L, C) < 0.1).astype(np.float32)
+  d = str(tmp_path / 'records')
+  os.makedirs(d)
+  # two train shards + one validation shard, named as the reference names them
+  T.write_segments(T.record_filename(d, 'train', 0, 2), sig[:6], spk[:6])
+  T.write_segments(T.record_filename(d, 'train', 1, 2), sig[6:n_train],
+                   spk[6:n_train])
+  T.write_segments(T.record_filename(d, 'validation', 0, 1), sig[n_train:],
+                   spk[n_train:])
+  assert sorted(os.listdir(d)) == [
+      'train-001-of-002.record', 'train-002-of-002.record',
+      'validation-001-of-001.record'
+  ]
+  info = dict(train_size=n_train, validation_size=n_val, signal_shape=(L, C),
+              spike_shape=(L, C), sequence_length=L, num_neurons=C,
+              num_channels=C, num_train_shards=2, num_validation_shards=1,
+              buffer_size=n_train, normalize=True, stride=2, fft=False,
+              conv2d=False, signals_min=0.0, signals_max=1.0)
+  with open(os.path.join(d, 'info.pkl'), 'wb') as f:
+    pickle.dump(info, f)
+  hp = SimpleNamespace(input_dir=d, output_dir=str(tmp_path / 'out'),
+                       batch_size=4, noise_dim=32, save_generated='')
+  train_ds, val_ds = dataset_helper.get_dataset(hp)
+  np.testing.assert_array_equal(train_ds.signals, sig[:n_train])
+  np.testing.assert_array_equal(train_ds.spikes, spk[:n_train])
+  np.testing.assert_array_equal(val_ds.signals, sig[n_train:])
+  assert hp.train_steps == 3 and hp.validation_steps == 1
+  assert hp.signal_shape == (L, C)
+  batches = [b for b, _ in val_ds]
+  assert batches[0].shape == (4, L, C) and batches[0].dtype == np.float32
+  # record framing: one flipped payload byte is a data-loss error, a short
+  # file a truncation error; verify=False reads past a bad checksum
+  path = T.record_filename(d, 'validation', 0, 1)
+  raw = bytearray(open(path, 'rb').read())
+  raw[40] ^= 0x01
+  bad = str(tmp_path / 'bad.record')
+  open(bad, 'wb').write(raw)
+  with pytest.raises(IOError):
+    list(T.read_records(bad))
+  assert len(list(T.read_records(bad, verify=False))) == n_val
+  open(bad, 'wb').write(bytes(raw[:-3]))
+  with pytest.raises(IOError):
+    list(T.read_records(bad, verify=False))
+  # an empty file holds no records
+  open(bad, 'wb').close()
+  assert list(T.read_records(bad)) == []
+
+
+def test_write_dataset_as_tfrecord_shards(tmp_path):
+  d = dg.make_dataset(num_neurons=8, sequence_length=64, num_segments=20)
+  info = {k: v for k, v in d['info'].items() if k != 'rates_hz'}
+  a = dataset_helper.write_dataset(str(tmp_path / 'npy'), d['signals'],
+                                   d['spikes'], info, validation_size=6)
+  b = dataset_helper.write_dataset(str(tmp_path / 'rec'), d['signals'],
+                                   d['spikes'], info, validation_size=6,
+                                   tfrecords=True, num_per_shard=5)
+  assert b['num_train_shards'] == 3 and b['num_validation_shards'] == 2
+  assert a['train_size'] == b['train_size'] == 14
+  out = []
+  for sub in ('npy', 'rec'):
+    hp = SimpleNamespace(input_dir=str(tmp_path / sub),
+                         output_dir=str(tmp_path / 'run'), batch_size=4,
+                         noise_dim=32, save_generated='')
+    out.append(dataset_helper.get_dataset(hp))
+  for k in (0, 1):  # same segments in the same order from both layouts
+    np.testing.assert_array_equal(out[0][k].signals, out[1][k].signals)
+    np.testing.assert_array_equal(out[0][k].spikes.astype(np.float32),
+                                  out[1][k].spikes)
