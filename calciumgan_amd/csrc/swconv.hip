@@ -449,11 +449,27 @@ struct PackArgs {
 
 // One thread packs one 16-byte group: 8 consecutive channels of one
 // (column n, chunk, tap) -- a single 16-byte store instead of eight 2-byte ones.
+// Thread order: when the source is contiguous in n (s_n == 1: the TF kernel
+// layout read as a forward operand) consecutive threads take consecutive n, so
+// each of the 8 gathers of a wave is one 256-byte run (the 16-byte stores are
+// then scattered, one instruction instead of eight); otherwise consecutive
+// threads follow the destination order and a thread's 8 channels are the
+// contiguous ones (s_c == 1).
 __device__ __forceinline__ void pack_group(const PackArgs& a, long long r) {
-  const int f = (int)(r % a.Fp);
-  long long q = r / a.Fp;
-  const int cc = (int)(q % a.nchunks);
-  const int n = (int)(q / a.nchunks);
+  int f, cc, n;
+  if (a.s_n == 1) {
+    const long long npad = a.total / 8 / ((long long)a.nchunks * a.Fp);
+    n = (int)(r % npad);
+    const long long q = r / npad;
+    f = (int)(q % a.Fp);
+    cc = (int)(q / a.Fp);
+    r = ((long long)n * a.nchunks + cc) * a.Fp + f;
+  } else {
+    f = (int)(r % a.Fp);
+    const long long q = r / a.Fp;
+    cc = (int)(q % a.nchunks);
+    n = (int)(q / a.nchunks);
+  }
   const int tap = f / a.c8;
   const int q8 = f - tap * a.c8;
   const int c = cc * a.CK + q8 * 8;
