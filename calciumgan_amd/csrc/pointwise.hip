@@ -701,6 +701,13 @@ __global__ __launch_bounds__(kThreads) void signal_metrics_kernel(
                                      part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+inline int rows_per_slot_for(long long rows, int rpw, int lo, int hi) {
+  long long want = rows / ((long long)rpw * 8192);
+  int rps = lo;
+  while (rps * 2 <= want && rps * 2 <= hi) rps *= 2;
+  return rps;
+}
+
 }  // namespace
 
 #define S_(x) ((hipStream_t)(x))
@@ -715,7 +722,9 @@ extern "C" int cg_ln_lrelu_fwd(const void* y_pre, const float* gamma,
   int lpr = 1, l2 = 0;
   while (lpr * 8 < Cp) { lpr <<= 1; ++l2; }
   const int rpw = 64 / lpr;
-  const int rows_per_slot = 8;
+  // rows per lane slot: enough waves to fill the chip (256 CUs x 32) before
+  // each wave gets a longer sequential run; a multiple of the load batch
+  const int rows_per_slot = rows_per_slot_for(rows, rpw, 4, 8);
   hipLaunchKernelGGL(ln_fwd_kernel,
                      dim3(grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31)),
                      dim3(kThreads), 0, S_(stream), U16(y_pre), gamma, beta,
@@ -733,7 +742,9 @@ extern "C" int cg_ln_lrelu_bwd(const void* dh, const void* h, const void* y_pre,
   int lpr = 1, l2 = 0;
   while (lpr * 8 < Cp) { lpr <<= 1; ++l2; }
   const int rpw = 64 / lpr;
-  const int rows_per_slot = 16;
+  // (longer runs than the forward: every block ends with 3*C global atomics
+  // onto the same addresses, which serialise -- fewer, longer blocks)
+  const int rows_per_slot = rows_per_slot_for(rows, rpw, 16, 64);
   hipLaunchKernelGGL(ln_bwd_kernel,
                      dim3(grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31)),
                      dim3(kThreads), 0, S_(stream), U16(dh), U16(h), U16(y_pre),
