@@ -1,0 +1,58 @@
+"""Worker of tests/test_parallel_gpu.py: one rank of a 2-rank data-parallel run
+of the real HIP train() (collectives over gloo so that both ranks can share the
+single GPU of the test box; the production backend is 'nccl' = RCCL and uses
+the same code).  Prints one JSON line per rank."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import oracle as O
+from calciumgan_amd import parallel
+
+
+def main():
+  parallel.init_process_group('gloo')
+  rank, world = parallel.rank(), parallel.world_size()
+  from calciumgan_amd.gan.algorithms import get_algorithm
+  from calciumgan_amd.gan.models import get_models
+  hp = O.make_hparams(256, 16, 32, kernel_size=24, m=2, layer_norm=True)
+  hp.verbose = 0
+  gen, dis = get_models(hp, None)          # same seed -> same initial weights
+  gan = get_algorithm(hp, gen, dis, None)
+  assert gan._sync.world == world
+  rng = np.random.RandomState(7)
+  full = rng.uniform(0, 1, (8 * world, 256, 16)).astype(np.float32)
+  mine = torch.tensor(full[rank::world]).to(gan.device)
+  losses = []
+  for _ in range(5):                        # 2 eager calls, then graph replays
+    gl, dl, gp, metrics = gan.train(mine)
+    losses.append([float(gl), float(dl), float(gp)])
+  torch.cuda.synchronize()
+  flat = torch.cat([gan.generator.net.params.data,
+                    gan.discriminator.net.params.data]).cpu()
+  gathered = [torch.empty_like(flat) for _ in range(world)]
+  dist.all_gather(gathered, flat)
+  same = all(torch.equal(gathered[0], g) for g in gathered)
+  z_other = [torch.empty(4) for _ in range(world)]
+  dist.all_gather(z_other, gan.get_noise(1)[0, :4].cpu())
+  print(json.dumps(dict(
+      rank=rank, world=world, weights_identical=bool(same),
+      finite=bool(np.isfinite(np.array(losses)).all()),
+      graphed=bool(gan._state[mine.shape[0]].get('graph') is not None),
+      segments=len(gan._state[mine.shape[0]]['graph']['graphs']),
+      noise_differs=bool(not torch.equal(z_other[0], z_other[1])),
+      moved=float((flat - gathered[0]).abs().max()), losses=losses[-1])),
+        flush=True)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -42,8 +42,38 @@ def no_barrier(s):
              '        const uint16_t* curB')
 
 
+def direct_b(s):
+  """Weights straight from global memory (L1/L2) into MFMA registers, one stage
+  ahead; no LDS ring, no DMA, no per-stage barrier.  Results stay correct."""
+  s = sub(s, '  issue_dma(0);\n  if (total_stages > 1) issue_dma(1);\n',
+          '  const uint16_t* wlane = wp + (long long)(n0 + wn * 64 + rM) * a.Kpack + g * 8;\n'
+          '  bf16x8 bnext[KS][KH][NT];\n'
+          '  auto load_b = [&](int gs) {\n'
+          '#pragma unroll\n    for (int ks = 0; ks < KS; ++ks)\n'
+          '#pragma unroll\n      for (int kh = 0; kh < KH; ++kh)\n'
+          '#pragma unroll\n        for (int nt = 0; nt < NT; ++nt)\n'
+          '          bnext[ks][kh][nt] = *reinterpret_cast<const bf16x8*>(\n'
+          '              wlane + (long long)nt * MF * a.Kpack +\n'
+          '              ((long long)gs * FS + 4 * ks + 2 * kh) * 8);\n'
+          '  };\n  load_b(0);\n')
+  i0 = s.index('        if (gs + 1 < total_stages)\n          asm volatile("s_waitcnt vmcnt(%0)"')
+  i1 = s.index('        const uint16_t* curB = ldsB + (gs % kNBufB) * kBufB;\n')
+  s = s[:i0] + (
+      '        bf16x8 bcur[KS][KH][NT];\n'
+      '#pragma unroll\n        for (int ks = 0; ks < KS; ++ks)\n'
+      '#pragma unroll\n          for (int kh = 0; kh < KH; ++kh)\n'
+      '#pragma unroll\n            for (int nt = 0; nt < NT; ++nt) bcur[ks][kh][nt] = bnext[ks][kh][nt];\n'
+      '        if (gs + 1 < total_stages) load_b(gs + 1);\n') + s[i1:]
+  s = sub(s, '        const uint16_t* curB = ldsB + (gs % kNBufB) * kBufB;\n', '')
+  s = sub(s, '              bfrag[nt] = *reinterpret_cast<const bf16x8*>(\n'
+             '                  curB + nt * MF * kRowB + boff[ks][kh]);\n',
+          '              bfrag[nt] = bcur[ks][kh][nt];\n')
+  return s
+
+
 VARIANTS = {
     'base': lambda s: s,
+    'directb': direct_b,
     'noepi': no_epilogue,
     'noa': no_a_staging,
     'nob': no_b_dma,
