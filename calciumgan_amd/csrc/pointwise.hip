@@ -261,26 +261,26 @@ __global__ __launch_bounds__(kThreads) void dense1_fwd_kernel(
   __shared__ float part[4];
   const int b = blockIdx.x;
   float s = 0.f;
-  constexpr int kNB = 4;  // 16-byte loads in flight per lane
+  constexpr int kNB = 4;  // activation / weight load pairs in flight per lane
   for (int i0 = threadIdx.x * 8; i0 < F; i0 += kNB * kThreads * 8) {
     uint4 raw[kNB];
+    float wv[kNB][8];
 #pragma unroll
     for (int k = 0; k < kNB; ++k) {
       const int i = i0 + k * kThreads * 8;
-      raw[k] = i < F ? ldg16(h + (long long)b * F + i)
-                     : make_uint4(0u, 0u, 0u, 0u);
+      const bool ok = i < F;
+      raw[k] = ok ? ldg16(h + (long long)b * F + i) : make_uint4(0u, 0u, 0u, 0u);
+      const int t = ok ? i / Cp : 0;
+      const int c = ok ? i - t * Cp : 0;
+      // w is (Lt, C) row-major: 8 consecutive channels of one timestep
+      load8f(w + (long long)t * C + c, ok ? C - c : 0, C, wv[k]);
     }
 #pragma unroll
     for (int k = 0; k < kNB; ++k) {
-      const int i = i0 + k * kThreads * 8;
-      if (i >= F) break;
       float v[8];
       unpack8(raw[k], v);
-      const int t = i / Cp;
-      const int c = i - t * Cp;
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (c + e < C) s += v[e] * bf2f(f2bf(w[t * C + c + e]));
+      for (int e = 0; e < 8; ++e) s += v[e] * bf2f(f2bf(wv[k][e]));
     }
   }
   s = wave_sum(s);
@@ -299,14 +299,15 @@ __global__ __launch_bounds__(kThreads) void dense1_bwd_kernel(
   const int b = (int)(idx / per_row);
   const int i = (int)(idx - (long long)b * per_row) * 8;
   const float c = coef[b / seg_size];
-  float vh[8], o[8];
-  load8(h + (long long)b * F + i, vh);
+  float vh[8], o[8], wv[8];
+  const uint4 raw = ldg16(h + (long long)b * F + i);
   const int t = i / Cp;
   const int ch = i - t * Cp;
+  load8f(w + (long long)t * C + ch, C - ch, C, wv);
+  unpack8(raw, vh);
 #pragma unroll
   for (int e = 0; e < 8; ++e)
-    o[e] = (ch + e < C) ? c * bf2f(f2bf(w[t * C + ch + e])) *
-                              (vh[e] > 0.f ? 1.f : alpha)
+    o[e] = (ch + e < C) ? c * bf2f(f2bf(wv[e])) * (vh[e] > 0.f ? 1.f : alpha)
                         : 0.f;
   store8(delta + (long long)b * F + i, o);
 }
