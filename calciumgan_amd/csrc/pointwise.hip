@@ -444,8 +444,7 @@ __global__ __launch_bounds__(kThreads) void cast_pad_kernel(
   const long long row = idx / per_row;
   const int c = (int)(idx - row * per_row) * 8;
   float v[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (c + e < C) ? src[row * Cs + c + e] : 0.f;
+  load8f(src + row * Cs + c, C - c, Cs, v);
   store8(dst + row * Cp + c, v);
 }
 
@@ -583,16 +582,11 @@ __global__ __launch_bounds__(kThreads) void sigmoid_bwd_kernel(
   const int per_row = Cp / 8;
   const long long row = idx / per_row;
   const int c = (int)(idx - row * per_row) * 8;
-  float o[8];
+  float o[8], sv[8], dv[8];
+  load8f(fake + row * Cf + c, C - c, Cf, sv);
+  load8f(dfake + row * Cp + c, C - c, Cp, dv);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float t = 0.f;
-    if (c + e < C) {
-      const float s = fake[row * Cf + c + e];
-      t = dfake[row * Cp + c + e] * s * (1.f - s);
-    }
-    o[e] = t;
-  }
+  for (int e = 0; e < 8; ++e) o[e] = dv[e] * sv[e] * (1.f - sv[e]);
   store8(dz + row * Cp + c, o);
 }
 
