@@ -184,24 +184,36 @@ def main():
   dt = time.perf_counter() - t0
   losses = [float(out[0]), float(out[1]), float(out[2])]
 
-  # Kernel-duration leg of the roofline: the SAME K steps again with a HIP
-  # event pair around every MFMA-kernel launch (recorded on the launch
-  # stream).  Single-process runs replay train() as one hipGraph in the timed
-  # region above, where events cannot be interposed, so this pass runs the
-  # identical kernels eagerly right after it (rank 0's numbers are reported).
+  # Kernel-duration leg of the roofline: the SAME K steps again with every
+  # MFMA-kernel launch timed by the library's launch profiler
+  # (cg_profile_enable: hipExtLaunchKernelGGL event pairs that carry the
+  # kernel's own begin / end timestamps on the launch stream, i.e. the figure
+  # rocprofv3 --kernel-trace reports).  Single-process runs replay train() as
+  # one hipGraph in the timed region above, where launches cannot be
+  # instrumented, so this pass runs the identical kernels eagerly right after
+  # it (rank 0's numbers are reported).
   records = []
   dt_prof = None
   if not args.no_kernel_timing:
+    import ctypes
+    from calciumgan_amd import _lib
+    lib = _lib.load()
+    cap = 512 * args.steps
     graphed = getattr(gan, '_use_graph', False)
     gan._use_graph = False
-    nets.set_profile(records)
+    _lib.check(lib.cg_profile_enable(cap), 'cg_profile_enable')
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(args.steps):
       gan.train(real)
     torch.cuda.synchronize()
     dt_prof = time.perf_counter() - t1
-    nets.set_profile(None)
+    ms = (ctypes.c_float * cap)()
+    famid = (ctypes.c_int * cap)()
+    n = lib.cg_profile_collect(ms, famid, cap)
+    if n < 0:
+      raise RuntimeError('cg_profile_collect: HIP error {}'.format(-n))
+    records = [(('swconv', 'wgrad')[famid[i]], ms[i] * 1e-3) for i in range(n)]
     gan._use_graph = graphed
 
   t = torch.tensor([dt], dtype=torch.float64, device=gan.device)
@@ -214,9 +226,9 @@ def main():
     value = world * B * args.steps / dt
     roofline = None
     fam = {}
-    for name, s, e in records:
+    for name, sec in records:
       d = fam.setdefault(name, [0.0, 0])
-      d[0] += s.elapsed_time(e) * 1e-3
+      d[0] += sec
       d[1] += 1
     if 'swconv' in fam:
       sec, cnt = fam['swconv']
@@ -230,7 +242,8 @@ def main():
           avg_launch_us=sec / cnt * 1e6,
           flop_per_launch=flops / cnt,
           share_of_step=sec / dt_prof,
-          timing='HIP event pairs around every launch, eager pass of the same '
+          timing='kernel begin/end timestamps of every launch '
+          '(hipExtLaunchKernelGGL event pairs), eager pass of the same '
           '{} steps run right after the timed region ({:.2f} ms/step '
           'eager vs {:.2f} ms/step timed)'.format(
               args.steps, dt_prof / args.steps * 1e3, dt / args.steps * 1e3))

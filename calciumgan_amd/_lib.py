@@ -73,6 +73,8 @@ class WgradDesc(C.Structure):
 SIGNATURES = {
     'cg_abi_version': [],
     'cg_tile_shape': [c_i, C.POINTER(c_i), C.POINTER(c_i)],
+    'cg_profile_enable': [c_i],
+    'cg_profile_collect': [C.POINTER(c_f), C.POINTER(c_i), c_i],
     'cg_swconv': [C.POINTER(ConvDesc), c_vp],
     'cg_packed_elems': [c_i, c_i, c_i, c_i],
     'cg_pack_weights': [C.POINTER(PackDesc), c_vp],

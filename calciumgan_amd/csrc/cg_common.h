@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 CalciumGAN kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/calciumgan_hip.h"
@@ -14,6 +15,24 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
   do {                                           \
     hipError_t e__ = hipGetLastError();          \
     return (int)e__;                             \
+  } while (0)
+
+// Kernel-precise timing of the MFMA launches (cg_profile_enable /
+// cg_profile_collect in the C ABI): while enabled, a launch is issued through
+// hipExtLaunchKernelGGL with an event pair that carries the kernel's own begin /
+// end timestamps (what rocprofv3 --kernel-trace reports), instead of events
+// recorded around the launch.  Defined in swconv.hip.
+#define CG_FAMILY_SWCONV 0
+#define CG_FAMILY_WGRAD 1
+bool cg_prof_next(int family, hipEvent_t* start, hipEvent_t* stop);
+#define CG_LAUNCH_PROF(family, kernel, grid, block, lds, stream, ...)          \
+  do {                                                                         \
+    hipEvent_t ps__, pe__;                                                     \
+    if (cg_prof_next(family, &ps__, &pe__))                                    \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ps__, pe__, 0,   \
+                            __VA_ARGS__);                                      \
+    else                                                                       \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);       \
   } while (0)
 
 __device__ __forceinline__ float bf2f(uint16_t v) {

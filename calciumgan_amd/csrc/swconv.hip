@@ -25,6 +25,7 @@
 //     goes through LDS so global stores are 16-byte and row-contiguous, with
 //     bias / LeakyReLU / LeakyReLU-derivative mask / sigmoid fused.
 #include <type_traits>
+#include <vector>
 
 #include "cg_common.h"
 
@@ -520,6 +521,56 @@ inline int ilog2(int v) {
 
 extern "C" int cg_abi_version(void) { return CG_ABI_VERSION; }
 
+// ---------------------------------------------------------------------------
+// launch profiler (process-wide, eager launches only; see cg_common.h)
+// ---------------------------------------------------------------------------
+namespace {
+struct ProfState {
+  std::vector<hipEvent_t> start, stop;
+  std::vector<int> family;
+  int used = 0;
+  bool on = false;
+} g_prof;
+}  // namespace
+
+bool cg_prof_next(int family, hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_prof.on || g_prof.used >= (int)g_prof.start.size()) return false;
+  *start = g_prof.start[g_prof.used];
+  *stop = g_prof.stop[g_prof.used];
+  g_prof.family[g_prof.used] = family;
+  ++g_prof.used;
+  return true;
+}
+
+extern "C" int cg_profile_enable(int max_launches) {
+  g_prof.used = 0;
+  g_prof.on = max_launches > 0;
+  while ((int)g_prof.start.size() < max_launches) {
+    hipEvent_t s, e;
+    hipError_t err = hipEventCreate(&s);
+    if (err == hipSuccess) err = hipEventCreate(&e);
+    if (err != hipSuccess) return (int)err;
+    g_prof.start.push_back(s);
+    g_prof.stop.push_back(e);
+    g_prof.family.push_back(0);
+  }
+  return 0;
+}
+
+extern "C" int cg_profile_collect(float* ms, int* family, int capacity) {
+  const int n = g_prof.used < capacity ? g_prof.used : capacity;
+  for (int i = 0; i < n; ++i) {
+    hipError_t err = hipEventSynchronize(g_prof.stop[i]);
+    if (err == hipSuccess)
+      err = hipEventElapsedTime(&ms[i], g_prof.start[i], g_prof.stop[i]);
+    if (err != hipSuccess) return -(int)err;
+    family[i] = g_prof.family[i];
+  }
+  g_prof.used = 0;
+  g_prof.on = false;
+  return n;
+}
+
 extern "C" long long cg_packed_elems(int N, int taps, int Cx, int CK) {
   if (CK < 32 || CK % 8 || Cx % CK || taps < 1 || N < 1) return -1;
   const int c8 = CK / 8;
@@ -614,8 +665,8 @@ static int launch_swconv1(const ConvArgs& a, dim3 grid, size_t lds,
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((swconv_kernel<R, MF, WGN, MT, KS, UNI>), grid, dim3(256),
-                     lds, stream, a);
+  CG_LAUNCH_PROF(CG_FAMILY_SWCONV, (swconv_kernel<R, MF, WGN, MT, KS, UNI>),
+                 grid, dim3(256), lds, stream, a);
   CG_LAUNCH_CHECK();
 }
 

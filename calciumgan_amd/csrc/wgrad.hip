@@ -341,8 +341,8 @@ int launch_wgrad1(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<R, TPW, ROWSPLIT, PIPE, TT>), grid,
-                     dim3(512), lds, s, a);
+  CG_LAUNCH_PROF(CG_FAMILY_WGRAD, (wgrad_kernel<R, TPW, ROWSPLIT, PIPE, TT>),
+                 grid, dim3(512), lds, s, a);
   CG_LAUNCH_CHECK();
 }
 

@@ -52,6 +52,17 @@ int cg_abi_version(void);
 /* rows / columns of a CG_TILE_* value (host helper; CG_EINVAL if unknown) */
 int cg_tile_shape(int tile, int* rows, int* cols);
 
+/* Measurement hook (the one piece of process-wide state in this library; not
+ * for use while a stream is being captured into a hipGraph).  After
+ * cg_profile_enable(n) the next n cg_swconv / cg_wgrad launches are issued with
+ * a HIP event pair that carries the kernel's own begin / end timestamps;
+ * cg_profile_collect waits for them, writes each launch's duration (ms) and
+ * family (0 = cg_swconv, 1 = cg_wgrad) in launch order, returns the count
+ * (negative hipError_t on failure) and disables the hook.  bench.py's roofline
+ * leg is its only user. */
+int cg_profile_enable(int max_launches);
+int cg_profile_collect(float* ms, int* family, int capacity);
+
 /* ---------------------------------------------------------------------------
  * Sliding-window convolution as an implicit GEMM on MFMA (bf16 in, f32 acc).
  *
