@@ -341,7 +341,10 @@ class WGAN_GP(GAN):
     for k, (fn, grad, wait) in enumerate(segs):
       graph = torch.cuda.CUDAGraph()
       graph.register_generator_state(self._streams.local)
-      with torch.cuda.graph(graph, pool=pool):
+      # thread_local: the RCCL watchdog thread may touch the HIP runtime while
+      # this thread captures
+      with torch.cuda.graph(graph, pool=pool,
+                            capture_error_mode='thread_local'):
         if k == 0:
           g['shifts_dev'].copy_(g['shifts_host'], non_blocking=True)
           g['lr_dev'].copy_(g['lr_host'], non_blocking=True)
