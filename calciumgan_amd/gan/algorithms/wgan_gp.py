@@ -338,21 +338,23 @@ class WGAN_GP(GAN):
     graphs = []
     pool = None
     torch.cuda.synchronize()
-    for k, (fn, grad, wait) in enumerate(segs):
-      graph = torch.cuda.CUDAGraph()
-      graph.register_generator_state(self._streams.local)
-      # thread_local: the RCCL watchdog thread may touch the HIP runtime while
-      # this thread captures
-      with torch.cuda.graph(graph, pool=pool,
-                            capture_error_mode='thread_local'):
-        if k == 0:
-          g['shifts_dev'].copy_(g['shifts_host'], non_blocking=True)
-          g['lr_dev'].copy_(g['lr_host'], non_blocking=True)
-        fn()
-      pool = graph.pool()
-      graphs.append((graph.replay, grad, wait))
-    # capture only records: undo the host-side step counters it advanced
-    self.dis_optimizer.iterations, self.gen_optimizer.iterations = it_d, it_g
+    try:
+      for k, (fn, grad, wait) in enumerate(segs):
+        graph = torch.cuda.CUDAGraph()
+        graph.register_generator_state(self._streams.local)
+        # thread_local: the RCCL watchdog thread may touch the HIP runtime
+        # while this thread captures
+        with torch.cuda.graph(graph, pool=pool,
+                              capture_error_mode='thread_local'):
+          if k == 0:
+            g['shifts_dev'].copy_(g['shifts_host'], non_blocking=True)
+            g['lr_dev'].copy_(g['lr_host'], non_blocking=True)
+          fn()
+        pool = graph.pool()
+        graphs.append((graph.replay, grad, wait))
+    finally:
+      # capture only records: undo the host-side step counters it advanced
+      self.dis_optimizer.iterations, self.gen_optimizer.iterations = it_d, it_g
     g['graphs'] = graphs
     g['out'] = out['value']
     return g
@@ -360,7 +362,17 @@ class WGAN_GP(GAN):
   def _train_graphed(self, real, st):
     g = st.get('graph')
     if g is None:
-      g = st['graph'] = self._capture(real, st)
+      try:
+        g = st['graph'] = self._capture(real, st)
+      except Exception as e:  # noqa: BLE001 -- any capture failure
+        # the step itself is unaffected: keep training with eager launches
+        import warnings
+        warnings.warn('calciumgan_amd: hipGraph capture of train() failed '
+                      '({}: {}); continuing with eager launches'.format(
+                          type(e).__name__, e))
+        self._use_graph = False
+        torch.cuda.synchronize()
+        return self._train_body(real)
     n = self.n_critic
     if g['real'].data_ptr() != real.data_ptr():
       g['real'].copy_(real)

@@ -1,7 +1,7 @@
 """Worker of tests/test_parallel_gpu.py: one rank of a 2-rank data-parallel run
 of the real HIP train() (collectives over gloo so that both ranks can share the
 single GPU of the test box; the production backend is 'nccl' = RCCL and uses
-the same code).  Prints one JSON line per rank."""
+the same code).  Writes one JSON record per rank into $DP_WORKER_OUT/rank<r>.json."""
 import json
 import os
 import sys
@@ -42,14 +42,20 @@ def main():
   same = all(torch.equal(gathered[0], g) for g in gathered)
   z_other = [torch.empty(4) for _ in range(world)]
   dist.all_gather(z_other, gan.get_noise(1)[0, :4].cpu())
-  print(json.dumps(dict(
+  rec = json.dumps(dict(
       rank=rank, world=world, weights_identical=bool(same),
       finite=bool(np.isfinite(np.array(losses)).all()),
       graphed=bool(gan._state[mine.shape[0]].get('graph') is not None),
       segments=len(gan._state[mine.shape[0]]['graph']['graphs']),
       noise_differs=bool(not torch.equal(z_other[0], z_other[1])),
-      moved=float((flat - gathered[0]).abs().max()), losses=losses[-1])),
-        flush=True)
+      moved=float((flat - gathered[0]).abs().max()), losses=losses[-1]))
+  # one file per rank: the ranks' stdout streams interleave (gloo's own
+  # connection messages land in the middle of lines)
+  out_dir = os.environ.get('DP_WORKER_OUT')
+  if out_dir:
+    with open(os.path.join(out_dir, 'rank{}.json'.format(rank)), 'w') as f:
+      f.write(rec)
+  print(rec, flush=True)
   dist.barrier()
   dist.destroy_process_group()
 

@@ -27,8 +27,9 @@ def _free_port():
   return p
 
 
-def test_two_rank_train_keeps_replicas_identical():
+def test_two_rank_train_keeps_replicas_identical(tmp_path):
   env = dict(os.environ)
+  env['DP_WORKER_OUT'] = str(tmp_path)
   env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
          '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
@@ -37,7 +38,8 @@ def test_two_rank_train_keeps_replicas_identical():
   out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True,
                        timeout=600)
   assert out.returncode == 0, out.stderr[-2000:]
-  recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
+  recs = [json.load(open(os.path.join(str(tmp_path), 'rank%d.json' % r)))
+          for r in (0, 1)]
   assert sorted(r['rank'] for r in recs) == [0, 1]
   for r in recs:
     assert r['world'] == 2
