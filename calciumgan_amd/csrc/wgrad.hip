@@ -51,7 +51,7 @@ __device__ __forceinline__ bf16x8 join(s16x4 lo, s16x4 hi) {
 
 // MFMA work of one staged tile: every wave reads its transposed fragments from
 // the row-major LDS images and accumulates its taps.
-template <int R, int TPW, bool ROWSPLIT, int TT>
+template <int R, int TPW, bool ROWSPLIT, int TT, bool ALLT>
 __device__ __forceinline__ void wgrad_compute(const WgradArgs& a,
                                               const uint16_t* ldsX,
                                               const uint16_t* ldsG,
@@ -59,6 +59,61 @@ __device__ __forceinline__ void wgrad_compute(const WgradArgs& a,
                                               int q, int p,
                                               f32x4 (&acc)[TPW][2][4]) {
   constexpr int KSTEPS = ROWSPLIT ? 1 : TT / 32;
+  if constexpr (ALLT) {
+    {
+      // Every wave owns TPW live taps and the tile is one sample (rows of the
+      // LDS images are linear): software-pipelined order.  The fragments of
+      // group n+1 (one x fragment = one (tap, 16-channel half); at a K-step
+      // boundary also the four g fragments of the next K-step) are read before
+      // the four MFMAs of group n issue, and scheduling barriers keep that
+      // order (left alone, hipcc sinks each read to just before its use: one
+      // exposed LDS round trip per eight MFMAs).  All addresses are one lane
+      // base per tap plus compile-time offsets.
+      constexpr int NI = 2 * TPW;
+      const uint16_t* gl = ldsG + (4 * g4 + q) * kPitchG + 4 * p;
+      const uint16_t* xl[TPW];
+#pragma unroll
+      for (int s = 0; s < TPW; ++s) {
+        const int tap = wave + 8 * s;
+        const int toff = R == 2 ? ((tap & 1) * regionRows + (tap >> 1)) * kPitchX
+                                : tap * kPitchX;
+        xl[s] = ldsX + (4 * g4 + q) * kPitchX + 4 * p + toff;
+      }
+      bf16x8 bfr[2][4], afr[2];
+      auto load_b = [&](int kstep, bf16x8 (&dst)[4]) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          dst[nt] = join(tr_read(gl + kstep * 32 * kPitchG + nt * 16),
+                         tr_read(gl + (kstep * 32 + 16) * kPitchG + nt * 16));
+      };
+      auto load_a = [&](int kstep, int i) {
+        const uint16_t* b = xl[i >> 1] + kstep * 32 * kPitchX + (i & 1) * 16;
+        return join(tr_read(b), tr_read(b + 16 * kPitchX));
+      };
+      load_b(0, bfr[0]);
+      afr[0] = load_a(0, 0);
+#pragma unroll
+      for (int kstep = 0; kstep < KSTEPS; ++kstep) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          if (i + 1 < NI) {
+            afr[(i + 1) & 1] = load_a(kstep, i + 1);
+          } else if (kstep + 1 < KSTEPS) {
+            // K-step boundary: the next step's g fragments ride along
+            load_b(kstep + 1, bfr[(kstep + 1) & 1]);
+            afr[0] = load_a(kstep + 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[i >> 1][i & 1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                afr[i & 1], bfr[kstep & 1][nt], acc[i >> 1][i & 1][nt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int kstep = 0; kstep < KSTEPS; ++kstep) {
     const int rbase = ROWSPLIT ? wave * 32 : kstep * 32;
@@ -122,7 +177,9 @@ __device__ __forceinline__ void colsum_tile(const uint16_t* ldsG, int m0,
 // split the staged rows (TT = 256) instead of the taps (TT = 64).  PIPE: one
 // sample per tile (nseg == 1): tiles are double-buffered in LDS and the next
 // tile's global loads are issued before the current tile's MFMAs.
-template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT>
+// ALLT: every wave owns TPW live taps (taps == 8 * TPW) and a tile is one
+// sample: wgrad_compute runs its software-pipelined order.
+template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, bool ALLT>
 __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(!ROWSPLIT || TT == 256, "row-split tiles are 256 rows");
@@ -237,7 +294,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
       const uint16_t* base = lds + cur * (bufX + bufG);
       if (do_bias && (long long)tile * TT < a.bias_rows)
         colsum_tile<TT>(base + bufX, tile * TT, a.bias_rows, tid, bs0, bs1);
-      wgrad_compute<R, TPW, ROWSPLIT, TT>(a, base, base + bufX, regionRows, wave,
+      wgrad_compute<R, TPW, ROWSPLIT, TT, ALLT>(a, base, base + bufX, regionRows, wave,
                                           g4, q, p, acc);
       if (more) {
         store_tile(lds + (cur ^ 1) * (bufX + bufG));
@@ -287,7 +344,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
       __syncthreads();
       if (do_bias && (long long)m0 < a.bias_rows)
         colsum_tile<TT>(ldsG, m0, a.bias_rows, tid, bs0, bs1);
-      wgrad_compute<R, TPW, ROWSPLIT, TT>(a, ldsX, ldsG, regionRows, wave, g4, q,
+      wgrad_compute<R, TPW, ROWSPLIT, TT, ALLT>(a, ldsX, ldsG, regionRows, wave, g4, q,
                                           p, acc);
     }
   }
@@ -330,18 +387,18 @@ inline int ilog2(int v) {
   return l;
 }
 
-template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT>
+template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, bool ALLT = false>
 int launch_wgrad1(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
-            &wgrad_kernel<R, TPW, ROWSPLIT, PIPE, TT>),
+            &wgrad_kernel<R, TPW, ROWSPLIT, PIPE, TT, ALLT>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  CG_LAUNCH_PROF(CG_FAMILY_WGRAD, (wgrad_kernel<R, TPW, ROWSPLIT, PIPE, TT>),
+  CG_LAUNCH_PROF(CG_FAMILY_WGRAD, (wgrad_kernel<R, TPW, ROWSPLIT, PIPE, TT, ALLT>),
                  grid, dim3(512), lds, s, a);
   CG_LAUNCH_CHECK();
 }
@@ -350,9 +407,18 @@ template <int R, int TPW, bool ROWSPLIT>
 int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, bool pipe, int tt,
                  hipStream_t s) {
   constexpr int T0 = ROWSPLIT ? 256 : 64;
-  if (!ROWSPLIT && tt == 128)  // only chosen with pipe
+  // pipe implies one sample per tile (nseg == 1)
+  const bool allt = !ROWSPLIT && pipe && a.taps == 8 * TPW && a.nseg == 1;
+  if (!ROWSPLIT && tt == 128) {  // only chosen with pipe
+    if (allt)
+      return launch_wgrad1<R, TPW, ROWSPLIT, true, ROWSPLIT ? 256 : 128,
+                           !ROWSPLIT>(a, grid, 2 * lds, s);
     return launch_wgrad1<R, TPW, ROWSPLIT, true, ROWSPLIT ? 256 : 128>(
         a, grid, 2 * lds, s);
+  }
+  if (pipe && allt)
+    return launch_wgrad1<R, TPW, ROWSPLIT, true, T0, !ROWSPLIT>(a, grid, 2 * lds,
+                                                                s);
   if (pipe) return launch_wgrad1<R, TPW, ROWSPLIT, true, T0>(a, grid, 2 * lds, s);
   return launch_wgrad1<R, TPW, ROWSPLIT, false, T0>(a, grid, lds, s);
 }
