@@ -84,8 +84,12 @@ constexpr int kScratchBytes = 4 * 16 * kScrPitch * 4;
 // workgroups per CU).  (The 128 x 64 wave tile holds 128 accumulator
 // registers: the second launch-bound argument keeps the rest within 128 so
 // two workgroups share a CU.)
+// (The PIPE instantiation -- 256-row 16x16x32 tile, two-K-step stages -- sits
+// at the edge of the three-waves-per-SIMD register budget: pin it there.)
 template <int R, int MF, int WGN, int MT, int KS, bool UNI>
-__global__ __launch_bounds__(256, (MF == 32 && MT == 4) ? 2 : 1) void
+__global__ __launch_bounds__(256, (MF == 32 && MT == 4)               ? 2
+                                  : (MF == 16 && MT == 4 && KS == 2 && UNI) ? 3
+                                                                     : 1) void
 swconv_kernel(ConvArgs a) {
   // PIPE: all fragment reads of a weight stage are issued ahead of its MFMAs
   // (see the stage loop); measured 2-5 % faster for the 256-row 16x16x32
@@ -237,6 +241,42 @@ swconv_kernel(ConvArgs a) {
                                                 q8 * 8);
           }
           *reinterpret_cast<uint4*>(ldsA + row * a.pitchA + q8 * 8) = v;
+        }
+      }
+    } else if (a.log2c8 >= 0) {
+      // several whole samples per tile (per-sample length < tile, so S == Lu
+      // and every segment starts at row 0 of its sample).  A thread keeps its
+      // 16-byte column; its window row advances by a constant step, carried
+      // into (sample, parity region) incrementally -- no per-piece divisions
+      const int q8 = tid & (a.c8 - 1);
+      const int rstep = 256 >> a.log2c8;
+      int row = tid >> a.log2c8;
+      int rho = row / regionRows;
+      int seg = (row - rho * regionRows) / a.WR;
+      int wr = row - rho * regionRows - seg * a.WR;
+      const int b0 = m0 / a.Lu;
+      const uint16_t* xq = a.x + cc * a.CK + q8 * 8;
+      uint16_t* dst = ldsA + row * a.pitchA + q8 * 8;
+      const int dstep = rstep * a.pitchA;
+      for (; row < R * regionRows; row += rstep) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        const int b = b0 + seg;
+        int srow = off + R * wr + rho;
+        if (b < a.nB && srow >= 0 && srow < a.Lx) {
+          if (a.shifts) srow = shuffle_src(srow, a.shifts[b / a.seg_size], a.Lx);
+          v = *reinterpret_cast<const uint4*>(
+              xq + ((long long)b * a.Lx + srow) * a.Cx);
+        }
+        *reinterpret_cast<uint4*>(dst) = v;
+        dst += dstep;
+        wr += rstep;
+        while (wr >= a.WR) {
+          wr -= a.WR;
+          ++seg;
+        }
+        if (seg >= a.nseg) {
+          seg -= a.nseg;
+          ++rho;
         }
       }
     } else {
