@@ -64,8 +64,8 @@ def algorithmic_flops(hp):
 def algorithmic_bytes_swconv(hp, B):
   """Algorithmic HBM bytes of all cg_swconv launches of one train(): every
   launch reads its bf16 source tensor and its packed bf16 weights once and
-  writes its output once (bf16, or f32 for the penalty gradient / generator
-  output).  Returns (bytes per step, launches per step)."""
+  writes its output once (bf16; f32 for the generator output).  Returns
+  (bytes per step, launches per step)."""
   from calciumgan_amd import geometry as geo
   k, n = hp.kernel_size, hp.n_critic
   g_l, d_l = geo.generator_layers(hp), geo.discriminator_layers(hp)
@@ -95,9 +95,9 @@ def algorithmic_bytes_swconv(hp, B):
   g_bwd += sum(convT_dgrad(B, l) for l in g_l)
   d_fwd = lambda nb: sum(conv(nb, l) for l in d_l)
   critic = g_fwd + d_fwd(3 * B) + sum(dgrad(3 * B, l) for l in d_l[1:])
-  critic += dgrad(B, d_l[0], 4) + d_fwd(B)  # x^ input gradient (f32) + tangent
+  critic += dgrad(B, d_l[0]) + d_fwd(B)  # x^ input gradient + tangent chain
   gen = g_fwd + d_fwd(B) + sum(dgrad(B, l) for l in d_l[1:]) + \
-      dgrad(B, d_l[0], 4) + g_bwd
+      dgrad(B, d_l[0]) + g_bwd
   launches = n * (7 + 5 + 4 + 1 + 5) + (7 + 5 + 4 + 1 + 6)
   return n * critic + gen, launches
 

@@ -448,17 +448,19 @@ __global__ __launch_bounds__(kThreads) void cast_pad_kernel(
   store8(dst + row * Cp + c, v);
 }
 
-// sumsq[b] += partial; grid (chunks, B)
+// sumsq[b] += partial of g bf16 [B][n]; grid (chunks, B)
 __global__ __launch_bounds__(kThreads) void sumsq_kernel(
-    const float* __restrict__ g, float* __restrict__ sumsq, long long n) {
+    const uint16_t* __restrict__ g, float* __restrict__ sumsq, long long n) {
   __shared__ float part[4];
   const int b = blockIdx.y;
-  const float* p = g + (long long)b * n;
+  const uint16_t* p = g + (long long)b * n;
   float s = 0.f;
-  for (long long i = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4; i < n;
-       i += (long long)gridDim.x * kThreads * 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
-    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  for (long long i = ((long long)blockIdx.x * kThreads + threadIdx.x) * 8; i < n;
+       i += (long long)gridDim.x * kThreads * 8) {
+    float v[8];
+    load8(p + i, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e] * v[e];
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
@@ -495,17 +497,17 @@ __global__ void gp_finalize_kernel(float* __restrict__ norm,
 }
 
 __global__ __launch_bounds__(kThreads) void scale_rows_kernel(
-    const float* __restrict__ g, const float* __restrict__ coef,
+    const uint16_t* __restrict__ g, const float* __restrict__ coef,
     uint16_t* __restrict__ a0, long long n, long long total8) {
   const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (idx >= total8) return;
   const long long i = idx * 8;
   const int b = (int)(i / n);
   const float c = coef[b];
-  const f32x4 v0 = *reinterpret_cast<const f32x4*>(g + i);
-  const f32x4 v1 = *reinterpret_cast<const f32x4*>(g + i + 4);
-  const float o[8] = {c * v0[0], c * v0[1], c * v0[2], c * v0[3],
-                      c * v1[0], c * v1[1], c * v1[2], c * v1[3]};
+  float v[8], o[8];
+  load8(g + i, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = c * v[e];
   store8(a0 + i, o);
 }
 
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(kThreads) void colsum_kernel(
 }
 
 __global__ __launch_bounds__(kThreads) void sigmoid_bwd_kernel(
-    const float* __restrict__ dfake, const float* __restrict__ fake,
+    const uint16_t* __restrict__ dfake, const float* __restrict__ fake,
     uint16_t* __restrict__ dz, int C, int Cf, int Cp, long long total8) {
   const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (idx >= total8) return;
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(kThreads) void sigmoid_bwd_kernel(
   const int c = (int)(idx - row * per_row) * 8;
   float o[8], sv[8], dv[8];
   load8f(fake + row * Cf + c, C - c, Cf, sv);
-  load8f(dfake + row * Cp + c, C - c, Cp, dv);
+  load8(dfake + row * Cp + c, dv);  // padding channels are zero in dfake
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = dv[e] * sv[e] * (1.f - sv[e]);
   store8(dz + row * Cp + c, o);
@@ -821,15 +823,15 @@ extern "C" int cg_cast_pad(const float* src, void* dst, long long rows, int C,
   CG_LAUNCH_CHECK();
 }
 
-extern "C" int cg_rownorm(const float* g, float* norm, int B, long long n,
+extern "C" int cg_rownorm(const void* g, float* norm, int B, long long n,
                           void* stream) {
-  if (n % 4 || B < 1) return CG_EINVAL;
+  if (n % 8 || B < 1) return CG_EINVAL;
   hipError_t e = hipMemsetAsync(norm, 0, sizeof(float) * B, S_(stream));
   if (e != hipSuccess) return (int)e;
-  int chunks = (int)((n / 4 + kThreads - 1) / kThreads);
+  int chunks = (int)((n / 8 + kThreads - 1) / kThreads);
   if (chunks > 64) chunks = 64;
   hipLaunchKernelGGL(sumsq_kernel, dim3(chunks, B), dim3(kThreads), 0,
-                     S_(stream), g, norm, n);
+                     S_(stream), U16(g), norm, n);
   hipLaunchKernelGGL(sqrt_kernel, dim3((B + 255) / 256), dim3(256), 0,
                      S_(stream), norm, B);
   CG_LAUNCH_CHECK();
@@ -842,12 +844,12 @@ extern "C" int cg_gp_finalize(float* norm, float* gp, float* coef, int B,
   CG_LAUNCH_CHECK();
 }
 
-extern "C" int cg_scale_rows(const float* g, const float* coef, void* a0, int B,
+extern "C" int cg_scale_rows(const void* g, const float* coef, void* a0, int B,
                              long long n, void* stream) {
   if (n % 8) return CG_EINVAL;
   const long long total8 = (long long)B * n / 8;
   hipLaunchKernelGGL(scale_rows_kernel, dim3(grid1d(total8, kThreads, 1LL << 31)),
-                     dim3(kThreads), 0, S_(stream), g, coef, U16W(a0), n,
+                     dim3(kThreads), 0, S_(stream), U16(g), coef, U16W(a0), n,
                      total8);
   CG_LAUNCH_CHECK();
 }
@@ -880,14 +882,15 @@ extern "C" int cg_colsum(const void* x, float* out, long long rows, int C,
   CG_LAUNCH_CHECK();
 }
 
-extern "C" int cg_sigmoid_bwd(const float* dfake, const float* fake, void* dz,
+extern "C" int cg_sigmoid_bwd(const void* dfake, const float* fake, void* dz,
                               long long rows, int C, int Cf, int Cp,
                               void* stream) {
   if (Cp % 8 || C > Cp || C > Cf) return CG_EINVAL;
   const long long total8 = rows * Cp / 8;
   hipLaunchKernelGGL(sigmoid_bwd_kernel,
                      dim3(grid1d(total8, kThreads, 1LL << 31)), dim3(kThreads),
-                     0, S_(stream), dfake, fake, U16W(dz), C, Cf, Cp, total8);
+                     0, S_(stream), U16(dfake), fake, U16W(dz), C, Cf, Cp,
+                     total8);
   CG_LAUNCH_CHECK();
 }
 

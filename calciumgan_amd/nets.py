@@ -492,8 +492,9 @@ class _DisPlan(object):
       op = net.w_dgrad[0]
       nG = nB - input_grad_from
       self.nG = nG
-      self.gin = torch.zeros(
-          nG, lay.lin, lay.cinp, dtype=torch.float32, device=dev)
+      # bf16 like every other activation gradient (its f32 sum of squares,
+      # the penalty norm, is taken in the producing launch's epilogue)
+      self.gin = torch.zeros(nG, lay.lin, lay.cinp, dtype=BF16, device=dev)
       # penalty norm fused into this launch's epilogue when a 256-row tile
       # never spans two samples; else the standalone cg_rownorm is used
       self.sumsq = None
@@ -502,7 +503,7 @@ class _DisPlan(object):
       self.input_grad = _conv_desc(
           ws.delta[1][input_grad_from:], op.buf, self.gin, nG, lay.lout,
           lay.coutp, k // 2, 1, net.dgrad_offs[0], lay.lin // 2, lay.cin,
-          lay.lin, lay.cinp, op.CK, y_stride=2, y_off=0, out_f32=True, nphase=2,
+          lay.lin, lay.cinp, op.CK, y_stride=2, y_off=0, nphase=2,
           w_phase_stride=op.elems,
           off_phase_step=net.dgrad_offs[1] - net.dgrad_offs[0],
           yoff_phase_step=1, rowsumsq=self.sumsq)
@@ -538,7 +539,7 @@ class _DisPlan(object):
 
   def backward_chain(self):
     """delta[5] = coef * w_d * lrelu'(h5); then down to delta[1]; optional
-    layer-1 input gradient into self.gin (f32)."""
+    layer-1 input gradient into self.gin (bf16)."""
     st = _stream()
     net, ws = self.ws.net, self.ws
     last = net.layers[-1]
@@ -744,8 +745,8 @@ class _GenWorkspace(object):
     _run_conv(self.f_out, st)
     return self.fake
 
-  def backward(self, dfake_f32):
-    """dfake (B, L, Cp) f32 = d loss / d fake -> accumulates every generator
+  def backward(self, dfake):
+    """dfake (B, L, Cp) bf16 = d loss / d fake -> accumulates every generator
     gradient into params.grad (caller zeroed it)."""
     net = self.net
     st = _stream()
@@ -753,11 +754,10 @@ class _GenWorkspace(object):
     V = net.params.views
     rows = self.B * net.L
     if net.normalize:
-      _lib.call('cg_sigmoid_bwd', _p(dfake_f32), _p(self.fake), _p(self.dz),
+      _lib.call('cg_sigmoid_bwd', _p(dfake), _p(self.fake), _p(self.dz),
                 rows, net.C, net.Cp, net.Cp, st)
     else:
-      _lib.call('cg_cast_pad', _p(dfake_f32), _p(self.dz), rows, net.C, net.Cp,
-                net.Cp, st)
+      self.dz.copy_(dfake.view_as(self.dz))  # linear output: dz = dfake
     _run_wgrad(self.b_out_wgrad, st)
     _lib.call('cg_colsum', _p(self.dz), _p(G[net.idx_out + 1]), rows, net.C,
               net.Cp, st)

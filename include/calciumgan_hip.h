@@ -227,15 +227,16 @@ int cg_interp_pack(const float* real, const float* fake, const float* alpha,
 /* dst bf16 [rows][Cp] = src f32 [rows][Cs] (C valid channels), pad zero */
 int cg_cast_pad(const float* src, void* dst, long long rows, int C, int Cs,
                 int Cp, void* stream);
-/* norm[b] = ||g[b]||_2 over n elements (wgan_gp.py:49), g f32 [B][n] */
-int cg_rownorm(const float* g, float* norm, int B, long long n, void* stream);
+/* norm[b] = ||g[b]||_2 over n elements (wgan_gp.py:49), g bf16 [B][n] (the
+ * layer-1 input gradient, stored like every other activation gradient) */
+int cg_rownorm(const void* g, float* norm, int B, long long n, void* stream);
 /* gp = mean((norm-1)^2) (wgan_gp.py:50); coef[b] = scale*2*(norm-1)/(B*norm).
  * squared != 0: `norm` holds sums of squares on entry and is replaced by their
  * square roots. */
 int cg_gp_finalize(float* norm, float* gp, float* coef, int B, float scale,
                    int squared, void* stream);
-/* a0 bf16 [B][n] = coef[b] * g[b] */
-int cg_scale_rows(const float* g, const float* coef, void* a0, int B,
+/* a0 bf16 [B][n] = coef[b] * g[b], g bf16 [B][n] */
+int cg_scale_rows(const void* g, const float* coef, void* a0, int B,
                   long long n, void* stream);
 /* out[0] = -mean(d_out[0:B]) + mean(d_out[B:2B]) + penalty*gp[0]  (wgan_gp.py:58-61)
  * out[1] = -mean(d_out[B:2B]) (generator_loss of the same fake batch) */
@@ -248,7 +249,7 @@ int cg_neg_mean(const float* d_out, float* out, int B, void* stream);
 int cg_colsum(const void* x, float* out, long long rows, int C, int Cp,
               void* stream);
 /* dz = dfake * s * (1 - s)  (sigmoid backward; calciumgan.py:98-99) */
-int cg_sigmoid_bwd(const float* dfake /*f32 [rows][Cp]*/,
+int cg_sigmoid_bwd(const void* dfake /*bf16 [rows][Cp]*/,
                    const float* fake /*f32 [rows][Cf]*/,
                    void* dz /*bf16 [rows][Cp]*/, long long rows, int C, int Cf,
                    int Cp, void* stream);

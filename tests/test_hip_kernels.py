@@ -498,7 +498,8 @@ def test_wgan_gp_elementwise_kernels():
   assert float(got[:, :, C:].abs().max()) == 0.0
   # penalty norm / finalize / scale
   g = torch.tensor(rng.randn(B, L * cp).astype(np.float32) * 0.05)
-  gd = g.to(H.DEV)
+  g = g.to(BF16).float()  # the input gradient is stored in bf16
+  gd = g.to(H.DEV).to(BF16)
   norm = torch.zeros(B, device=H.DEV)
   gp = torch.zeros(1, device=H.DEV)
   coef = torch.zeros(B, device=H.DEV)
@@ -563,7 +564,8 @@ def test_adam_colsum_sigmoid_lrelu_metrics():
   dfake = torch.zeros(1, rows, cp)
   dfake[:, :, :C] = torch.tensor(rng.randn(1, rows, C).astype(np.float32))
   dz = torch.zeros(1, rows, cp, dtype=BF16, device=H.DEV)
-  dfake_d, fake_d = dfake.to(H.DEV), fake.to(H.DEV)
+  dfake = dfake.to(BF16).float()  # arrives as a bf16 activation gradient
+  dfake_d, fake_d = dfake.to(H.DEV).to(BF16), fake.to(H.DEV)
   _lib.call('cg_sigmoid_bwd', H.p(dfake_d), H.p(fake_d), H.p(dz), rows, C, C,
             cp, H.stream())
   H.sync()
