@@ -41,6 +41,8 @@ class ConvDesc(C.Structure):
       ('tile', c_i),
       ('stage_ksteps', c_i),
       ('rowsumsq', c_vp),
+      ('w_parity_major', c_i),
+      ('split_parity', c_i),
   ]
 
 
@@ -51,6 +53,7 @@ class PackDesc(C.Structure):
       ('taps', c_i), ('tap0', c_i), ('tap_step', c_i),
       ('s_tap', c_ll), ('s_c', c_ll), ('s_n', c_ll),
       ('C_real', c_i), ('N_real', c_i), ('Cx', c_i), ('CK', c_i),
+      ('parity_major', c_i),
   ]
 
 

@@ -52,6 +52,7 @@ struct ConvArgs {
   long long w_phase_stride;
   int off_phase_step, yoff_phase_step;
   int gm, gn, gp;  // logical grid: row tiles, column tiles, phases
+  int pmajor;      // stride 2: weights packed even taps first, then odd taps
 };
 
 // LDS row pitches, 16x16x32: 2*odd 16-byte slots: with the MFMA operand map
@@ -86,11 +87,17 @@ constexpr int kScratchBytes = 4 * 16 * kScrPitch * 4;
 // two workgroups share a CU.)
 // (The PIPE instantiation -- 256-row 16x16x32 tile, two-K-step stages -- sits
 // at the edge of the three-waves-per-SIMD register budget: pin it there.)
-template <int R, int MF, int WGN, int MT, int KS, bool UNI>
+// SP (stride 2, parity-major weights): the window of a channel chunk is staged
+// one source-row parity at a time -- half the LDS, so a 256-row stride-2 tile
+// leaves room for a third workgroup on the CU -- at twice the staging phases.
+template <int R, int MF, int WGN, int MT, int KS, bool UNI, bool SP = false>
 __global__ __launch_bounds__(256, (MF == 32 && MT == 4)               ? 2
                                   : (MF == 16 && MT == 4 && KS == 2 && UNI) ? 3
                                                                      : 1) void
 swconv_kernel(ConvArgs a) {
+  static_assert(!SP || (R == 2 && UNI), "split-parity staging is a stride-2 mode");
+  constexpr int NREG = SP ? 1 : R;  // parity regions resident in LDS at a time
+  constexpr int NPART = SP ? 2 : 1; // staging parts per channel chunk
   // PIPE: all fragment reads of a weight stage are issued ahead of its MFMAs
   // (see the stage loop); measured 2-5 % faster for the 256-row 16x16x32
   // tile with two-K-step stages, where the 16 fragments fit the register
@@ -155,7 +162,7 @@ swconv_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < MF * MF / 64; ++r) acc[mt][nt][r] = 0.f;
 
-  const int totalA = R * regionRows * a.c8;
+  const int totalA = NREG * regionRows * a.c8;
   // B staging by LDS-DMA: wave w issues instructions j = w*NDMA + i, each
   // writing LDS bytes [j KiB, (j+1) KiB) of the ring slot; lane L lands at byte
   // j*1024 + L*16 = (row, slot c'), and fetches global chunk c = c' ^ swz(row).
@@ -195,8 +202,18 @@ swconv_kernel(ConvArgs a) {
   issue_dma(0);
   if (total_stages > 1) issue_dma(1);
 
-  for (int cc = 0; cc < a.nchunks; ++cc) {
-    __syncthreads();  // previous chunk's fragment reads are done
+  const int nst_part = nstages / NPART;  // weight stages per staged part
+  const int half_taps = a.taps >> 1;
+  int tap = 0;              // position in the packed tap order
+  int q8l = UNI ? 0 : g;    // 16-byte group inside the tap (c8 >= 4)
+  for (int ccp = 0; ccp < a.nchunks * NPART; ++ccp) {
+    const int cc = ccp / NPART;
+    const int part = ccp % NPART;  // SP: the source-row parity staged now
+    if (part == 0) {
+      tap = 0;
+      q8l = UNI ? 0 : g;
+    }
+    __syncthreads();  // previous part's fragment reads are done
     // ---- stage the source window of this channel chunk ------------------
     if (a.nseg == 1) {
       // fast path (per-sample length >= tile): one sample per tile, no
@@ -216,9 +233,9 @@ swconv_kernel(ConvArgs a) {
         const uint16_t* xq = xb + q8 * 8;
         uint16_t* dst = ldsA + (tid >> a.log2c8) * a.pitchA + q8 * 8;
         const int dstep = rstep * a.pitchA;
-        for (int row = tid >> a.log2c8; row < R * a.WR; row += rstep) {
-          const int rho = (R == 2 && row >= a.WR) ? 1 : 0;
-          int srow = srow0 + R * (row - rho * a.WR) + rho;
+        for (int row = tid >> a.log2c8; row < NREG * a.WR; row += rstep) {
+          const int rho = SP ? part : ((R == 2 && row >= a.WR) ? 1 : 0);
+          int srow = srow0 + R * (SP ? row : row - rho * a.WR) + rho;
           uint4 v = make_uint4(0u, 0u, 0u, 0u);
           if (valid && srow >= 0 && srow < a.Lx) {
             if (a.shifts) srow = shuffle_src(srow, sft, a.Lx);
@@ -231,8 +248,8 @@ swconv_kernel(ConvArgs a) {
         for (int idx = tid; idx < totalA; idx += 256) {
           const int row = __float2int_rz(((float)idx + 0.5f) * a.inv_c8);
           const int q8 = idx - row * a.c8;
-          const int rho = (R == 2 && row >= a.WR) ? 1 : 0;
-          const int wr = row - rho * a.WR;
+          const int rho = SP ? part : ((R == 2 && row >= a.WR) ? 1 : 0);
+          const int wr = SP ? row : row - rho * a.WR;
           int srow = srow0 + R * wr + rho;
           uint4 v = make_uint4(0u, 0u, 0u, 0u);
           if (valid && srow >= 0 && srow < a.Lx) {
@@ -251,14 +268,15 @@ swconv_kernel(ConvArgs a) {
       const int q8 = tid & (a.c8 - 1);
       const int rstep = 256 >> a.log2c8;
       int row = tid >> a.log2c8;
-      int rho = row / regionRows;
+      int rho = SP ? 0 : row / regionRows;
       int seg = (row - rho * regionRows) / a.WR;
       int wr = row - rho * regionRows - seg * a.WR;
+      if (SP) rho = part;
       const int b0 = m0 / a.Lu;
       const uint16_t* xq = a.x + cc * a.CK + q8 * 8;
       uint16_t* dst = ldsA + row * a.pitchA + q8 * 8;
       const int dstep = rstep * a.pitchA;
-      for (; row < R * regionRows; row += rstep) {
+      for (; row < NREG * regionRows; row += rstep) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         const int b = b0 + seg;
         int srow = off + R * wr + rho;
@@ -274,7 +292,7 @@ swconv_kernel(ConvArgs a) {
           wr -= a.WR;
           ++seg;
         }
-        if (seg >= a.nseg) {
+        if (!SP && seg >= a.nseg) {
           seg -= a.nseg;
           ++rho;
         }
@@ -311,10 +329,8 @@ swconv_kernel(ConvArgs a) {
     // wave-uniform (scalar registers, lane part g*8 folded into the row base);
     // otherwise (e.g. c8 = 13) every lane tracks its own (tap, group).
     {
-      int tap = 0;
-      int q8l = UNI ? 0 : g;  // c8 >= 4
       const int goff = UNI ? g * 8 : 0;
-      for (int s = 0; s < nstages; ++s) {
+      for (int s = part * nst_part; s < (part + 1) * nst_part; ++s) {
         const int gs = cc * nstages + s;
         // stage gs has landed once all but this wave's newest NDMA DMAs are
         // done (only DMA(gs+1) may stay in flight); the barrier then (a) makes
@@ -335,12 +351,19 @@ swconv_kernel(ConvArgs a) {
         // "all reads, one wait, 16*KS MFMAs back to back".
         bf16x8 afrag[2][KH][MT], bfrag[2][KH][NT];
         auto read_frags = [&](int buf, int ks) {
-          const int t = tap < a.taps ? tap : a.taps - 1;  // padded K: B is zero
+          const int ti = tap < a.taps ? tap : a.taps - 1;  // padded K: B is zero
           int aoff;
-          if (R == 2)
-            aoff = ((t & 1) * regionRows + (t >> 1)) * a.pitchA + q8l * 8;
-          else
-            aoff = t * a.pitchA + q8l * 8;
+          if (R == 2) {
+            // packed position -> tap (parity-major operands: evens, then odds)
+            const int t = !a.pmajor       ? ti
+                          : ti < half_taps ? 2 * ti
+                                           : 2 * (ti - half_taps) + 1;
+            // SP: only the parity region of this part is resident, at row 0
+            aoff = ((SP ? 0 : (t & 1) * regionRows) + (t >> 1)) * a.pitchA +
+                   q8l * 8;
+          } else {
+            aoff = ti * a.pitchA + q8l * 8;
+          }
 #pragma unroll
           for (int kh = 0; kh < KH; ++kh) {
 #pragma unroll
@@ -514,6 +537,7 @@ struct PackArgs {
   long long s_tap, s_c, s_n;
   int C_real, N_real, CK, c8, nchunks, Fp;
   long long Kpack, total;
+  int parity_major;  // packed tap i holds tap 2i (i < taps/2) else 2(i-taps/2)+1
 };
 
 // One thread packs one 16-byte group: 8 consecutive channels of one
@@ -546,7 +570,11 @@ __device__ __forceinline__ void pack_group(const PackArgs& a, long long r) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = 0.f;
   if (tap < a.taps && n < a.N_real) {
-    const float* src = a.src + (long long)(a.tap0 + tap * a.tap_step) * a.s_tap +
+    const int half = a.taps >> 1;
+    const int tsrc = !a.parity_major ? tap
+                     : tap < half   ? 2 * tap
+                                    : 2 * (tap - half) + 1;
+    const float* src = a.src + (long long)(a.tap0 + tsrc * a.tap_step) * a.s_tap +
                        n * a.s_n;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -653,6 +681,7 @@ static int fill_pack_args(const cg_pack_desc* d, PackArgs& a) {
   a.src = d->src;
   a.dst = reinterpret_cast<uint16_t*>(d->dst);
   a.taps = d->taps; a.tap0 = d->tap0; a.tap_step = d->tap_step;
+  a.parity_major = d->parity_major;
   a.s_tap = d->s_tap; a.s_c = d->s_c; a.s_n = d->s_n;
   a.C_real = d->C_real; a.N_real = d->N_real; a.CK = d->CK;
   a.c8 = d->CK / 8; a.nchunks = d->Cx / d->CK;
@@ -709,6 +738,7 @@ extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {
   a.src = d->src;
   a.dst = reinterpret_cast<uint16_t*>(d->dst);
   a.taps = d->taps; a.tap0 = d->tap0; a.tap_step = d->tap_step;
+  a.parity_major = d->parity_major;
   a.s_tap = d->s_tap; a.s_c = d->s_c; a.s_n = d->s_n;
   a.C_real = d->C_real; a.N_real = d->N_real; a.CK = d->CK;
   a.c8 = d->CK / 8; a.nchunks = d->Cx / d->CK;
@@ -722,25 +752,29 @@ extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {
   CG_LAUNCH_CHECK();
 }
 
-template <int R, int MF, int WGN, int MT, int KS, bool UNI>
+template <int R, int MF, int WGN, int MT, int KS, bool UNI, bool SP = false>
 static int launch_swconv1(const ConvArgs& a, dim3 grid, size_t lds,
                           hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&swconv_kernel<R, MF, WGN, MT, KS, UNI>),
+        reinterpret_cast<const void*>(
+            &swconv_kernel<R, MF, WGN, MT, KS, UNI, SP>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  CG_LAUNCH_PROF(CG_FAMILY_SWCONV, (swconv_kernel<R, MF, WGN, MT, KS, UNI>),
+  CG_LAUNCH_PROF(CG_FAMILY_SWCONV, (swconv_kernel<R, MF, WGN, MT, KS, UNI, SP>),
                  grid, dim3(256), lds, stream, a);
   CG_LAUNCH_CHECK();
 }
 
 template <int R, int MF, int WGN, int MT, int KS>
-static int launch_swconv(const ConvArgs& a, dim3 grid, size_t lds,
+static int launch_swconv(const ConvArgs& a, dim3 grid, size_t lds, bool sp,
                          hipStream_t stream) {
+  if constexpr (R == 2) {
+    if (sp) return launch_swconv1<R, MF, WGN, MT, KS, true, true>(a, grid, lds, stream);
+  }
   if ((a.c8 & 3) == 0)
     return launch_swconv1<R, MF, WGN, MT, KS, true>(a, grid, lds, stream);
   if constexpr (MF == 16)
@@ -818,7 +852,11 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   a.S = S; a.log2S = ilog2(S); a.nseg = TM / S;
   a.WR = S + d->taps / R - 1;
   if (d->rowsumsq && a.nseg != 1) return CG_EINVAL;  // one sample per tile
-  a.ldsA_elems = R * a.nseg * a.WR * a.pitchA;
+  // stride-2 operand order / split-parity staging
+  a.pmajor = (R == 2 && d->w_parity_major) ? 1 : 0;
+  const bool sp = R == 2 && d->split_parity != 0;
+  if (sp && (!a.pmajor || (a.c8 & 3) || (d->taps & 1))) return CG_EINVAL;
+  a.ldsA_elems = (sp ? 1 : R) * a.nseg * a.WR * a.pitchA;
   a.epilogue = d->epilogue; a.out_f32 = d->out_f32; a.alpha = d->alpha;
   a.w_phase_stride = d->w_phase_stride;
   a.off_phase_step = d->off_phase_step;
@@ -838,6 +876,9 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   if (d->stage_ksteps == 2 || d->stage_ksteps == 4) ks = d->stage_ksteps;
   const size_t lds = ldsA_bytes + ldsB_bytes(ks, TN);
   if (lds > 160 * 1024) return CG_EINVAL;
+  // each parity's taps must fill whole weight stages (no K padding in between)
+  if (sp && (a.Fp != d->taps * a.c8 || ((d->taps / 2) * a.c8) % (4 * ks)))
+    return CG_EINVAL;
   a.gm = (a.M + TM - 1) / TM;
   a.gn = (d->N + TN - 1) / TN;
   a.gp = d->nphase;
@@ -845,7 +886,7 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
 #define CG_DISPATCH(RR, FF, WW, MM, KK)                                   \
   if (R == RR && tc.mf == FF && tc.wgn == WW && tc.mt == MM && ks == KK) \
-    return launch_swconv<RR, FF, WW, MM, KK>(a, grid, lds, s);
+    return launch_swconv<RR, FF, WW, MM, KK>(a, grid, lds, sp, s);
 #define CG_DISPATCH_RK(FF, WW, MM)                              \
   CG_DISPATCH(1, FF, WW, MM, 4) CG_DISPATCH(2, FF, WW, MM, 4) \
   CG_DISPATCH(1, FF, WW, MM, 2) CG_DISPATCH(2, FF, WW, MM, 2)

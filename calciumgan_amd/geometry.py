@@ -55,7 +55,8 @@ def tile_rows(Lu, M, n_tiles_n):
       'multiple of 64)'.format(Lu))
 
 
-def lds_bytes(CK, stride, taps, Lu, TM, TN=64, mfma_rows=16):
+def lds_bytes(CK, stride, taps, Lu, TM, TN=64, mfma_rows=16,
+              split_parity=False):
   """Smallest dynamic LDS of a cg_swconv launch (64-deep weight stages)."""
   c8 = CK // 8
   if mfma_rows == 16:
@@ -65,7 +66,8 @@ def lds_bytes(CK, stride, taps, Lu, TM, TN=64, mfma_rows=16):
   S = min(Lu, TM)
   nseg = TM // S
   WR = S + taps // stride - 1
-  a = max(stride * nseg * WR * pitch_a * 2, _SCRATCH)
+  regions = 1 if (split_parity and stride == 2) else stride
+  a = max(regions * nseg * WR * pitch_a * 2, _SCRATCH)
   return round_up(a, 16) + _LDS_B * (TN // 64)
 
 

@@ -83,8 +83,12 @@ class PackedOperand(object):
   """bf16 MFMA operand of one (layer, direction), produced from the f32 master
   tensor by cg_pack_weights in the K order cg_swconv walks."""
 
-  def __init__(self, src, phases, C_real, N_real, Cx, CK, taps):
+  def __init__(self, src, phases, C_real, N_real, Cx, CK, taps,
+               parity_major=False):
+    """parity_major: even taps first, then odd taps -- the order a stride-2
+    launch walks them with w_parity_major (needed for split-parity staging)."""
     lib = _lib.load()
+    self.parity_major = bool(parity_major)
     self.elems = lib.cg_packed_elems(N_real, taps, Cx, CK)
     if self.elems < 0:
       raise ValueError('bad packing geometry')
@@ -101,6 +105,7 @@ class PackedOperand(object):
       d.taps, d.tap0, d.tap_step = taps, tap0, tap_step
       d.s_tap, d.s_c, d.s_n = s_tap, s_c, s_n
       d.C_real, d.N_real, d.Cx, d.CK = C_real, N_real, Cx, CK
+      d.parity_major = int(self.parity_major)
       self.descs.append(d)
 
   def repack(self):
@@ -172,8 +177,10 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
                y_stride=1, y_off=0, bias=None, mask_src=None, shifts=None,
                seg_size=1, epilogue=_lib.EPI_NONE, out_f32=False, nphase=1,
                w_phase_stride=0, off_phase_step=0, yoff_phase_step=0,
-               rowsumsq=None):
+               rowsumsq=None, w_parity_major=False):
   d = ConvDesc()
+  d.w_parity_major = int(bool(w_parity_major) and stride == 2)
+  d.split_parity = 0
   d._keep = (x, w, y, bias, mask_src, shifts, rowsumsq)  # borrowed pointers
   d.rowsumsq = rowsumsq.data_ptr() if rowsumsq is not None else None
   d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
@@ -260,7 +267,13 @@ def _autotune_tile(d):
       if ok and geo.lds_bytes(d.CK, d.stride, d.taps, d.Lu, tm, tn,
                               mf) <= geo.LDS_BYTES:
         cands.append(small)
-    cands = [(small, ks) for small in cands for ks in (2, 4)]
+    cands = [(small, ks, 0) for small in cands for ks in (2, 4)]
+    if d.stride == 2 and d.w_parity_major:
+      # split-parity staging: half the LDS window, twice the staging phases
+      cands += [(small, ks, 1) for small, ks, _ in list(cands)
+                if geo.lds_bytes(d.CK, 2, d.taps, d.Lu, _lib.TILES[small][0],
+                                 _lib.TILES[small][1], _lib.TILES[small][2],
+                                 split_parity=True) <= geo.LDS_BYTES]
     times = {}
     y_saved = d.y
     scratch = None
@@ -270,9 +283,10 @@ def _autotune_tile(d):
       nbytes = d.nB * d.Ly * d.Cy * (4 if d.out_f32 else 2)
       scratch = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
       d.y = scratch.data_ptr()
-    for small, ks in cands:
+    for small, ks, sp in cands:
       d.tile = small
       d.stage_ksteps = ks
+      d.split_parity = sp
       if lib.cg_swconv(ctypes.byref(d), st) != 0:
         continue
       s = torch.cuda.Event(enable_timing=True)
@@ -282,14 +296,15 @@ def _autotune_tile(d):
         lib.cg_swconv(ctypes.byref(d), st)
       e.record()
       e.synchronize()
-      times[(small, ks)] = s.elapsed_time(e)
+      times[(small, ks, sp)] = s.elapsed_time(e)
     d.y = y_saved
+    d.split_parity = 0
     del scratch
     if not times:
       return
     best = min(times, key=times.get)
     _TILE_CACHE[key] = best
-  d.tile, d.stage_ksteps = best
+  d.tile, d.stage_ksteps, d.split_parity = best
 
 
 def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,
@@ -385,7 +400,7 @@ class DiscriminatorNet(object):
       ck = _ck_for(lay.cinp, 2, self.k, lay.lout)
       self.w_fwd.append(
           PackedOperand(W, [(0, 1, ci * co, co, 1)], ci, co, lay.cinp, ck,
-                        self.k))
+                        self.k, parity_major=True))
       ck = _ck_for(lay.coutp, 1, self.k // 2, lay.lin // 2)
       self.w_dgrad.append(
           PackedOperand(W, [(t0, -2, ci * co, 1, co) for t0, _ in phases], co,
@@ -466,7 +481,7 @@ class _DisPlan(object):
           _conv_desc(ws.act[i], op.buf, ws.act[i + 1], nB, lay.lin, lay.cinp, k,
                      2, -pl, lay.lout, lay.cout, lay.lout, lay.coutp, op.CK,
                      bias=bias, shifts=sh, seg_size=seg_size,
-                     epilogue=_lib.EPI_LRELU))
+                     epilogue=_lib.EPI_LRELU, w_parity_major=op.parity_major))
       self.wgrad.append(
           _wgrad_desc(ws.act[i], ws.delta[i + 1], net.params.grad_views[2 * i],
                       nB, lay.lin, lay.cinp, lay.lout, lay.coutp, k, 2, -pl,
@@ -524,7 +539,8 @@ class _DisPlan(object):
           _conv_desc(ws.act[i][s0:s0 + n], op.buf, seg_act, n, lay.lin,
                      lay.cinp, k, 2, -pl, lay.lout, lay.cout, lay.lout,
                      lay.coutp, op.CK, mask_src=seg_act, shifts=sh,
-                     seg_size=n, epilogue=_lib.EPI_MASK))
+                     seg_size=n, epilogue=_lib.EPI_MASK,
+                     w_parity_major=op.parity_major))
 
   # -- schedules ------------------------------------------------------------
   def forward(self):
@@ -642,7 +658,7 @@ class GeneratorNet(object):
       ck = _ck_for(lay.coutp, 2, self.k, lay.lin)
       self.w_dgrad.append(
           PackedOperand(W, [(0, 1, co * ci, ci, 1)], co, ci, lay.coutp, ck,
-                        self.k))
+                        self.k, parity_major=True))
     Wo = V[self.idx_out]
     ck = _ck_for(self.Cp, 1, 1, self.L)
     self.w_out = PackedOperand(Wo, [(0, 1, 0, self.C, 1)], self.C, self.C,
@@ -720,7 +736,8 @@ class _GenWorkspace(object):
       op = net.w_dgrad[i]
       self.b_dgrad.append(
           _conv_desc(self.dy[i + 1], op.buf, self.dh[i], B, lay.lout, lay.coutp,
-                     k, 2, -net.pl, lay.lin, lay.cin, lay.lin, lay.cinp, op.CK))
+                     k, 2, -net.pl, lay.lin, lay.cin, lay.lin, lay.cinp, op.CK,
+                     w_parity_major=op.parity_major))
       self.b_wgrad.append(
           _wgrad_desc(self.dy[i + 1], self.h[i], G[ic], B, lay.lout, lay.coutp,
                       lay.lin, lay.cinp, k, 2, -net.pl, lay.cout, lay.cin))

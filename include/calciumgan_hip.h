@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 2
+#define CG_ABI_VERSION 3
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -106,6 +106,10 @@ typedef struct cg_conv_desc {
   int stage_ksteps;     /* 0: choose; 2 or 4: MFMA K-steps per weight stage */
   float* rowsumsq;      /* optional f32 [nB]: += sum over (row, n) of y^2 per
                            sample (penalty norm, wgan_gp.py:49); needs Lu >= tile */
+  int w_parity_major;   /* stride 2: `w` was packed with parity_major = 1 */
+  int split_parity;     /* stride 2 + w_parity_major: stage one source-row
+                           parity at a time (half the LDS window, twice the
+                           staging phases; results identical) */
 } cg_conv_desc;
 
 int cg_swconv(const cg_conv_desc* d, void* stream);
@@ -126,6 +130,10 @@ typedef struct cg_pack_desc {
   int taps, tap0, tap_step;
   long long s_tap, s_c, s_n;
   int C_real, N_real, Cx, CK;
+  int parity_major; /* 0: taps in order; 1 (even taps only): the even taps first,
+                       then the odd ones -- the order in which a stride-2 launch
+                       with w_parity_major walks them (one source-row parity
+                       at a time) */
 } cg_pack_desc;
 int cg_pack_weights(const cg_pack_desc* d, void* stream);
 /* Batched form (one launch for all operands of a model).  Host side:

@@ -36,8 +36,9 @@ def int_tensor(rng, shape, lo=-3, hi=3, scale=1.0):
       rng.randint(lo, hi + 1, size=shape).astype(np.float32) * scale)
 
 
-def pack(src_dev, phases, C_real, N_real, Cx, CK, taps):
-  op = nets.PackedOperand(src_dev, phases, C_real, N_real, Cx, CK, taps)
+def pack(src_dev, phases, C_real, N_real, Cx, CK, taps, parity_major=False):
+  op = nets.PackedOperand(src_dev, phases, C_real, N_real, Cx, CK, taps,
+                          parity_major=parity_major)
   op.repack()
   return op
 

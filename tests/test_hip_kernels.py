@@ -89,24 +89,26 @@ def test_conv_fwd_bitexact(nB, L, Ci, Co, k, seg, use_shift):
 ALL_TILES = [(t, ks) for t in sorted(_lib.TILES) for ks in (2, 4)]
 
 
-def _force_tile(d, tile, ks):
+def _force_tile(d, tile, ks, sp=0):
   """Override the autotuned choice; skip when the shape does not admit the
   tile (cg_swconv answers CG_EINVAL and launches nothing)."""
-  d.tile, d.stage_ksteps = tile, ks
+  d.tile, d.stage_ksteps, d.split_parity = tile, ks, sp
   rc = _lib.load().cg_swconv(ctypes.byref(d), H.stream())
   if rc == _lib.CG_EINVAL:
     pytest.skip('tile %d not admissible for this shape' % tile)
   assert rc == 0
 
 
+@pytest.mark.parametrize('sp', [0, 1])
 @pytest.mark.parametrize('tile,ks', ALL_TILES)
 @pytest.mark.parametrize('nB,L,Ci,Co,k,seg', [(2, 1024, 64, 192, 24, 1),
                                               (6, 128, 96, 102, 24, 2),
                                               (3, 512, 32, 64, 8, 3)])
-def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg):
+def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp):
   """Stride-2 forward with phase shuffle + bias + LeakyReLU on every workgroup
   tile (both MFMA shapes, 4x1 and 2x2 waves) and both weight-stage depths,
-  including partial column tiles (192, 102) and several samples per tile."""
+  including partial column tiles (192, 102) and several samples per tile;
+  sp = 1: parity-major weights with split-parity window staging."""
   rng = np.random.RandomState(2)
   x = H.int_tensor(rng, (nB, L, Ci))
   W = H.int_tensor(rng, (k, Ci, Co), -2, 2, 0.5)
@@ -119,14 +121,16 @@ def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg):
   Lo = L // 2
   pl = geo.same_padding_left(k, 2)
   ck = nets._ck_for(cip, 2, k, Lo)
-  op = H.pack(W.to(H.DEV), [(0, 1, Ci * Co, Co, 1)], Ci, Co, cip, ck, k)
+  op = H.pack(W.to(H.DEV), [(0, 1, Ci * Co, Co, 1)], Ci, Co, cip, ck, k,
+              parity_major=bool(sp))
   xd = H.to_pitch(x, cip)
   y = torch.full((nB, Lo, cop), 7.0, dtype=BF16, device=H.DEV)
   sh = torch.tensor(shifts, device=H.DEV)
   bd = b.to(H.DEV)
   d = H.conv_desc(xd, op.buf, y, nB, L, cip, k, 2, -pl, Lo, Co, Lo, cop, ck,
-                  bias=bd, shifts=sh, seg_size=seg, epilogue=_lib.EPI_LRELU)
-  _force_tile(d, tile, ks)
+                  bias=bd, shifts=sh, seg_size=seg, epilogue=_lib.EPI_LRELU,
+                  w_parity_major=bool(sp))
+  _force_tile(d, tile, ks, sp)
   H.sync()
   got = y.float().cpu()
   np.testing.assert_array_equal(got[:, :, :Co].numpy(), ref.numpy())
