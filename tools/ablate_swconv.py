@@ -20,7 +20,7 @@ def sub(s, old, new):
 
 def no_epilogue(s):
   return sub(
-      s, '  // ---- epilogue: accumulators -> LDS -> row-contiguous 16-byte stores ----\n',
+      s, '  // ---- epilogue: accumulators -> LDS -> whole-line row-contiguous stores ----\n',
       '  {\n    float sacc = 0.f;\n    for (int mt = 0; mt < MT; ++mt)\n'
       '      for (int nt = 0; nt < NT; ++nt) sacc += acc[mt][nt][0];\n'
       '    if (sacc == 12345.f) reinterpret_cast<float*>(a.y)[0] = sacc;\n'
@@ -65,9 +65,9 @@ def direct_b(s):
       '#pragma unroll\n            for (int nt = 0; nt < NT; ++nt) bcur[ks][kh][nt] = bnext[ks][kh][nt];\n'
       '        if (gs + 1 < total_stages) load_b(gs + 1);\n') + s[i1:]
   s = sub(s, '        const uint16_t* curB = ldsB + (gs % kNBufB) * kBufB;\n', '')
-  s = sub(s, '              bfrag[nt] = *reinterpret_cast<const bf16x8*>(\n'
+  s = sub(s, '              bfrag[buf][kh][nt] = *reinterpret_cast<const bf16x8*>(\n'
              '                  curB + nt * MF * kRowB + boff[ks][kh]);\n',
-          '              bfrag[nt] = bcur[ks][kh][nt];\n')
+          '              bfrag[buf][kh][nt] = bcur[ks][kh][nt];\n')
   return s
 
 

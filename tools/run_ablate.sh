@@ -1,7 +1,7 @@
 #!/bin/bash
 # times the ablated swconv builds (tools/ablate_swconv.py) on two layers
 B=tools/bench_conv.py
-for v in base noepi noa nob nobar noab loop; do
+for v in base noepi noa nob nobar noab loop directb; do
   export CALCIUMGAN_HIP_LIB=$PWD/tools/probe/_abl/lib_$v.so
   export CALCIUMGAN_AUTOTUNE=0
   echo "== $v"
