@@ -54,11 +54,17 @@ def algorithmic_flops(hp):
   f_g, f_d = 2.0 * macs_g, 2.0 * macs_d
   f_d1 = 2.0 * d_layers[0].lout * k * d_layers[0].cin * d_layers[0].cout
   n = hp.n_critic
-  swconv = n * (f_g + 7 * f_d - 2 * f_d1) + 2 * f_g + 2 * f_d
+  # the generator's last Dense runs in the streaming cg_dense_rows kernel
+  # (HBM-bound, not part of the swconv family) whenever its shape allows
+  f_dense = 2.0 * hp.signal_shape[0] * hp.num_channels * hp.num_channels
+  streaming = geo.pitch(hp.num_channels) <= 128
+  dense_rows = (n + 1) * f_dense if streaming else 0.0
+  swconv = n * (f_g + 7 * f_d - 2 * f_d1) + 2 * f_g + 2 * f_d - dense_rows
   wgrad = n * 3 * f_d + f_g
   total = (n + 3) * f_g + (10 * n + 2) * f_d - 2 * n * f_d1
-  assert abs(total - swconv - wgrad) < 1e-3 * total
-  return dict(total=total, swconv=swconv, wgrad=wgrad, f_g=f_g, f_d=f_d)
+  assert abs(total - swconv - wgrad - dense_rows) < 1e-3 * total
+  return dict(total=total, swconv=swconv, wgrad=wgrad, f_g=f_g, f_d=f_d,
+              dense_rows=dense_rows)
 
 
 def algorithmic_bytes_swconv(hp, B):
@@ -90,7 +96,9 @@ def algorithmic_bytes_swconv(hp, B):
 
   g_fwd = B * (nd * 2 + w0 * nd * 2) + nd * w0 * nd * 2
   g_fwd += sum(convT(B, l) for l in g_l)
-  g_fwd += B * L * (cp * 2 + cp * 4) + cp * C * 2
+  streaming = cp <= 128  # last Dense in cg_dense_rows, not a swconv launch
+  if not streaming:
+    g_fwd += B * L * (cp * 2 + cp * 4) + cp * C * 2
   g_bwd = B * L * (cp * 2 + cp * 2) + cp * C * 2
   g_bwd += sum(convT_dgrad(B, l) for l in g_l)
   d_fwd = lambda nb: sum(conv(nb, l) for l in d_l)
@@ -98,7 +106,8 @@ def algorithmic_bytes_swconv(hp, B):
   critic += dgrad(B, d_l[0]) + d_fwd(B)  # x^ input gradient + tangent chain
   gen = g_fwd + d_fwd(B) + sum(dgrad(B, l) for l in d_l[1:]) + \
       dgrad(B, d_l[0]) + g_bwd
-  launches = n * (7 + 5 + 4 + 1 + 5) + (7 + 5 + 4 + 1 + 6)
+  g_launches = 6 if streaming else 7
+  launches = n * (g_launches + 5 + 4 + 1 + 5) + (g_launches + 5 + 4 + 1 + 6)
   return n * critic + gen, launches
 
 

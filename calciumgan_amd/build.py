@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libcalciumgan_hip.so')
-SOURCES = ['swconv.hip', 'wgrad.hip', 'pointwise.hip']
+SOURCES = ['swconv.hip', 'wgrad.hip', 'pointwise.hip', 'dense_rows.hip']
 HEADERS = ['cg_common.h', os.path.join('..', '..', 'include',
                                        'calciumgan_hip.h')]
 

@@ -759,7 +759,14 @@ class _GenWorkspace(object):
                   _p(V[ic + 3]), _p(self.h[i + 1]), _p(self.mean[i + 1]),
                   _p(self.rstd[i + 1]), self.B * lay.lout, lay.cout, lay.coutp,
                   LN_EPS, LEAKY_ALPHA, st)
-    _run_conv(self.f_out, st)
+    if net.Cp <= 128 and net.w_out.CK == 32:
+      # HBM-bound per-timestep Dense (+ sigmoid): the streaming kernel
+      _lib.call('cg_dense_rows', _p(self.h[-1]), _p(net.w_out.buf),
+                _p(V[net.idx_out + 1]), _p(self.fake), self.B * net.L, net.Cp,
+                net.C, net.Cp,
+                _lib.EPI_SIGMOID if net.normalize else _lib.EPI_NONE, st)
+    else:
+      _run_conv(self.f_out, st)
     return self.fake
 
   def backward(self, dfake):

@@ -113,6 +113,16 @@ typedef struct cg_conv_desc {
 } cg_conv_desc;
 
 int cg_swconv(const cg_conv_desc* d, void* stream);
+
+/* Streaming form of the 1-tap case with f32 output (the generator's last
+ * layers.Dense + sigmoid, calciumgan.py:96-101; HBM-bound):
+ *   y[r, n] = epi(bias[n] + sum_c x[r, c] * W[c][n]),  y[r, n >= N] = 0
+ * x bf16 [rows][Cx], y f32 [rows][Cy]; `w` is the cg_pack_weights operand for
+ * (taps 1, Cx, CK 32).  Supported: Cx in {32, 64, 96, 128}, N <= Cy <= 128,
+ * Cy % 4 == 0, epilogue CG_EPI_NONE or CG_EPI_SIGMOID. */
+int cg_dense_rows(const void* x, const void* w, const float* bias, float* y,
+                  long long rows, int Cx, int N, int Cy, int epilogue,
+                  void* stream);
 /* elements (bf16) of one packed phase operand for (N, taps, Cx, CK) */
 long long cg_packed_elems(int N, int taps, int Cx, int CK);
 

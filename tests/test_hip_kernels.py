@@ -294,6 +294,35 @@ def test_dense_sigmoid_and_mask_epilogues():
       rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize('rows,Ci,Co,epi', [(1000, 102, 102, 3), (77, 32, 6, 0),
+                                            (4096, 128, 128, 3), (33, 64, 40, 0)])
+def test_dense_rows_streaming(rows, Ci, Co, epi):
+  """cg_dense_rows == the 1-tap cg_swconv it replaces for the generator's last
+  Dense (+ sigmoid): exact on integer data without activation, f32 tolerance
+  with the sigmoid; padding channels zero; ragged row count."""
+  rng = np.random.RandomState(21)
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  x = H.int_tensor(rng, (1, rows, Ci), -3, 3)
+  W = H.int_tensor(rng, (Ci, Co), -2, 2, 0.25)
+  b = H.int_tensor(rng, (Co,), -2, 2, 0.5)
+  op = H.pack(W.to(H.DEV), [(0, 1, 0, Co, 1)], Ci, Co, cip, 32, 1)
+  y = torch.full((rows, cop), 9.0, dtype=torch.float32, device=H.DEV)
+  xd = H.to_pitch(x, cip)
+  bd = b.to(H.DEV)
+  _lib.call('cg_dense_rows', H.p(xd), H.p(op.buf), H.p(bd), H.p(y), rows, cip,
+            Co, cop, epi, H.stream())
+  H.sync()
+  ref = x[0] @ W + b
+  got = y.cpu()
+  if epi == 3:
+    np.testing.assert_allclose(got[:, :Co].numpy(), torch.sigmoid(ref).numpy(),
+                               rtol=2e-6, atol=1e-6)
+  else:
+    np.testing.assert_array_equal(got[:, :Co].numpy(), ref.numpy())
+  if cop > Co:
+    assert float(got[:, Co:].abs().max()) == 0.0
+
+
 WGRAD_CASES = [
     (3, 128, 102, 64, 24, 1, True),
     (2, 64, 16, 40, 24, 2, False),
