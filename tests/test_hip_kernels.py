@@ -295,7 +295,8 @@ def test_dense_sigmoid_and_mask_epilogues():
 
 
 @pytest.mark.parametrize('rows,Ci,Co,epi', [(1000, 102, 102, 3), (77, 32, 6, 0),
-                                            (4096, 128, 128, 3), (33, 64, 40, 0)])
+                                            (4096, 128, 128, 3), (33, 64, 40, 0),
+                                            (50, 96, 70, 3)])
 def test_dense_rows_streaming(rows, Ci, Co, epi):
   """cg_dense_rows == the 1-tap cg_swconv it replaces for the generator's last
   Dense (+ sigmoid): exact on integer data without activation, f32 tolerance
