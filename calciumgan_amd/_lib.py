@@ -86,6 +86,7 @@ SIGNATURES = {
     'cg_pack_plan_build': [C.POINTER(PackDesc), c_i, c_vp, c_ll],
     'cg_pack_batched': [c_vp, c_i, c_ll, c_vp],
     'cg_wgrad': [C.POINTER(WgradDesc), c_vp],
+    'cg_wgrad_batched': [C.POINTER(WgradDesc), c_i, c_vp],
     'cg_ln_lrelu_fwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_f,
                         c_f, c_vp],
     'cg_ln_lrelu_bwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,

@@ -179,8 +179,12 @@ __device__ __forceinline__ void colsum_tile(const uint16_t* ldsG, int m0,
 // tile's global loads are issued before the current tile's MFMAs.
 // ALLT: every wave owns TPW live taps (taps == 8 * TPW) and a tile is one
 // sample: wgrad_compute runs its software-pipelined order.
+// (bx, by, bz) / gz: this workgroup's (cx chunk, cg chunk, K' split) and the
+// number of K' splits -- blockIdx / gridDim.z for a single launch, decoded from
+// the linear block id by the multi-layer kernel below.
 template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, bool ALLT>
-__global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
+                                           int bz, int gz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(!ROWSPLIT || TT == 256, "row-split tiles are 256 rows");
   constexpr int NG = TT * 8 / 512;  // g pieces per thread (1, 2 or 4)
@@ -196,8 +200,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   const int g4 = lane >> 4;
   const int q = r16 >> 2;
   const int p = r16 & 3;
-  const int cx0 = blockIdx.x * 32;
-  const int cg0 = blockIdx.y * 64;
+  const int cx0 = bx * 32;
+  const int cg0 = by * 64;
 
   f32x4 acc[TPW][2][4];
 #pragma unroll
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
 
   const int totalX = R * regionRows * 4;
   const int totalG = TT * 8;
-  const bool do_bias = a.dbias != nullptr && blockIdx.x == 0;
+  const bool do_bias = a.dbias != nullptr && bx == 0;
   float bs0 = 0.f, bs1 = 0.f;
 
   if (PIPE) {
@@ -280,8 +284,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
             gr[j];
     };
 
-    const int stride = gridDim.z;
-    int tile = blockIdx.z;
+    const int stride = gz;
+    int tile = bz;
     int cur = 0;
     if (tile < a.ntiles) {
       load_tile(tile);
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   } else {
     uint16_t* ldsX = lds;
     uint16_t* ldsG = lds + bufX;
-    for (int tile = blockIdx.z; tile < a.ntiles; tile += gridDim.z) {
+    for (int tile = bz; tile < a.ntiles; tile += gz) {
       const int m0 = tile * TT;
       __syncthreads();
       for (int idx = tid; idx < totalX; idx += 512) {
@@ -381,6 +385,43 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   }
 }
 
+template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, bool ALLT>
+__global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
+  wgrad_body<R, TPW, ROWSPLIT, PIPE, TT, ALLT>(a, blockIdx.x, blockIdx.y,
+                                               blockIdx.z, gridDim.z);
+}
+
+// Several layers' weight gradients in ONE launch: workgroup b does item b of
+// layer 0, then item b of layer 1, ...  Every workgroup ends an item by adding
+// its 196 KB of accumulators into dW with fire-and-forget f32 atomics; inside
+// one launch those drain while the workgroup already runs the next layer's
+// main loop, instead of holding the whole chip at a kernel boundary (24-38 us
+// per layer as separate launches).
+constexpr int kMaxBatch = 6;
+struct WgradMulti {
+  int n;
+  int gx[kMaxBatch], gy[kMaxBatch], gz[kMaxBatch], tt[kMaxBatch];
+  WgradArgs a[kMaxBatch];
+};
+
+template <int R, int TPW>
+__global__ __launch_bounds__(512) void wgrad_multi_kernel(WgradMulti m) {
+  for (int li = 0; li < m.n; ++li) {
+    const int gx = m.gx[li], gy = m.gy[li], gz = m.gz[li];
+    const int id = blockIdx.x;
+    if (id < gx * gy * gz) {
+      const int bx = id % gx;
+      const int by = (id / gx) % gy;
+      const int bz = id / (gx * gy);
+      if (m.tt[li] == 128)
+        wgrad_body<R, TPW, false, true, 128, true>(m.a[li], bx, by, bz, gz);
+      else
+        wgrad_body<R, TPW, false, true, 64, true>(m.a[li], bx, by, bz, gz);
+    }
+    __syncthreads();  // LDS is reused by the next item
+  }
+}
+
 inline int ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
@@ -425,7 +466,16 @@ int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, bool pipe, int tt,
 
 }  // namespace
 
-extern "C" int cg_wgrad(const cg_wgrad_desc* d, void* stream) {
+namespace {
+
+struct WgradPlan {
+  WgradArgs a;
+  int gx, gy, nsplit, TT, R, tpw;
+  size_t lds;
+  bool pipe, rowsplit;
+};
+
+int plan_wgrad(const cg_wgrad_desc* d, WgradPlan& p) {
   if (!d || !d->x || !d->g || !d->dw) return CG_EINVAL;
   const bool rowsplit = d->taps == 1;
   if (rowsplit) {
@@ -449,7 +499,7 @@ extern "C" int cg_wgrad(const cg_wgrad_desc* d, void* stream) {
     if (TT % d->Lu) return CG_EINVAL;
     S = d->Lu;
   }
-  WgradArgs a;
+  WgradArgs& a = p.a;
   a.x = reinterpret_cast<const uint16_t*>(d->x);
   a.g = reinterpret_cast<const uint16_t*>(d->g);
   a.dw = d->dw;
@@ -467,23 +517,97 @@ extern "C" int cg_wgrad(const cg_wgrad_desc* d, void* stream) {
   const size_t lds =
       ((size_t)R * a.nseg * a.WR * kPitchX + (size_t)TT * kPitchG) * 2;
   if (lds > 160 * 1024) return CG_EINVAL;
-  const bool pipe = a.nseg == 1 && 2 * lds <= 160 * 1024;
-  const int gx = (d->Cx_real + 31) / 32;
-  const int gy = (d->Cg_real + 63) / 64;
+  p.pipe = a.nseg == 1 && 2 * lds <= 160 * 1024;
+  p.gx = (d->Cx_real + 31) / 32;
+  p.gy = (d->Cg_real + 63) / 64;
   int nsplit = d->nsplit;
   if (nsplit <= 0) {
-    // one 8-wave workgroup per CU is resident (152 VGPRs); every extra K'
-    // split costs a full dW tile of f32 atomics (chip-wide ~1.3 TB/s), so
-    // split just enough to fill the 256 CUs once
-    nsplit = 256 / (gx * gy);
+    // one 8-wave workgroup per CU is resident; every extra K' split costs a
+    // full dW tile of f32 atomics (chip-wide ~1.8 TB/s), so split just enough
+    // to fill the 256 CUs once
+    nsplit = 256 / (p.gx * p.gy);
     if (nsplit < 1) nsplit = 1;
   }
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   if (nsplit < 1) nsplit = 1;
-  dim3 grid(gx, gy, nsplit);
+  p.nsplit = nsplit;
+  p.TT = TT; p.R = R; p.lds = lds; p.rowsplit = rowsplit;
+  p.tpw = rowsplit ? 1 : (d->taps <= 8 ? 1 : (d->taps <= 16 ? 2 : 3));
+  return 0;
+}
+
+int launch_plan(const WgradPlan& p, hipStream_t s) {
+  dim3 grid(p.gx, p.gy, p.nsplit);
+  if (p.rowsplit)
+    return launch_wgrad<1, 1, true>(p.a, grid, p.lds, p.pipe, p.TT, s);
+  if (p.tpw == 1)
+    return launch_wgrad<2, 1, false>(p.a, grid, p.lds, p.pipe, p.TT, s);
+  if (p.tpw == 2)
+    return launch_wgrad<2, 2, false>(p.a, grid, p.lds, p.pipe, p.TT, s);
+  return launch_wgrad<2, 3, false>(p.a, grid, p.lds, p.pipe, p.TT, s);
+}
+
+template <int TPW>
+int launch_multi(const WgradMulti& m, int blocks, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&wgrad_multi_kernel<2, TPW>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  CG_LAUNCH_PROF(CG_FAMILY_WGRAD, (wgrad_multi_kernel<2, TPW>), dim3(blocks),
+                 dim3(512), lds, s, m);
+  CG_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+extern "C" int cg_wgrad(const cg_wgrad_desc* d, void* stream) {
+  WgradPlan p;
+  const int rc = plan_wgrad(d, p);
+  if (rc) return rc;
+  return launch_plan(p, (hipStream_t)stream);
+}
+
+extern "C" int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream) {
+  if (!descs || n < 1) return CG_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (rowsplit) return launch_wgrad<1, 1, true>(a, grid, lds, pipe, TT, s);
-  if (d->taps <= 8) return launch_wgrad<2, 1, false>(a, grid, lds, pipe, TT, s);
-  if (d->taps <= 16) return launch_wgrad<2, 2, false>(a, grid, lds, pipe, TT, s);
-  return launch_wgrad<2, 3, false>(a, grid, lds, pipe, TT, s);
+  WgradPlan plans[kMaxBatch];
+  bool fuse = n >= 2 && n <= kMaxBatch;
+  for (int i = 0; i < n && i < kMaxBatch; ++i) {
+    const int rc = plan_wgrad(descs + i, plans[i]);
+    if (rc) return rc;
+    const WgradPlan& p = plans[i];
+    // the fused kernel is the pipelined stride-2 instantiation with every tap
+    // live; anything else is launched on its own
+    if (p.rowsplit || !p.pipe || p.a.taps != 8 * p.tpw || p.a.nseg != 1 ||
+        p.tpw != plans[0].tpw)
+      fuse = false;
+  }
+  if (!fuse) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = cg_wgrad(descs + i, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  WgradMulti m;
+  m.n = n;
+  int blocks = 0;
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    const WgradPlan& p = plans[i];
+    m.a[i] = p.a;
+    m.gx[i] = p.gx; m.gy[i] = p.gy; m.gz[i] = p.nsplit; m.tt[i] = p.TT;
+    const int nb = p.gx * p.gy * p.nsplit;
+    if (nb > blocks) blocks = nb;
+    if (2 * p.lds > lds) lds = 2 * p.lds;
+  }
+  switch (plans[0].tpw) {
+    case 1: return launch_multi<1>(m, blocks, lds, s);
+    case 2: return launch_multi<2>(m, blocks, lds, s);
+    default: return launch_multi<3>(m, blocks, lds, s);
+  }
 }

@@ -350,6 +350,21 @@ def _run_conv(d, st):
   _timed('cg_swconv', 'swconv', d, st)
 
 
+_BATCH_WGRAD = __import__('os').environ.get('CALCIUMGAN_WGRAD_BATCH', '1') != '0'
+
+
+def _run_wgrads(descs, st):
+  """Independent weight gradients of one backward pass as one cg_wgrad_batched
+  call (a single launch when they share the pipelined stride-2 form: each
+  layer's accumulator flush then overlaps the next layer's main loop)."""
+  if _PROFILE is not None or len(descs) == 1 or not _BATCH_WGRAD:
+    for d in descs:
+      _run_wgrad(d, st)
+    return
+  arr = (WgradDesc * len(descs))(*descs)
+  _lib.call('cg_wgrad_batched', arr, len(descs), st)
+
+
 def _run_wgrad(d, st):
   _timed('cg_wgrad', 'wgrad', d, st)
 
@@ -586,7 +601,7 @@ class _DisPlan(object):
     net, ws = self.ws.net, self.ws
     for i, d in enumerate(self.wgrad):
       d.bias_rows = bias_rows * net.layers[i].lout
-      _run_wgrad(d, st)
+    _run_wgrads(self.wgrad, st)
     last = net.layers[-1]
     _lib.call('cg_dense1_wgrad', _p(ws.act[-1]), _p(self.coef),
               _p(self.bias_coef), _p(net.params.grad_views[-2]),
@@ -800,13 +815,15 @@ class _GenWorkspace(object):
                   _p(self.dy[i + 1]), n * lay.coutp, LEAKY_ALPHA, st)
         _lib.call('cg_colsum', _p(self.dy[i + 1]), _p(G[ic + 1]), n, lay.cout,
                   lay.coutp, st)
-      _run_wgrad(self.b_wgrad[i], st)
       _run_conv(self.b_dgrad[i], st)
     nflat = net.w0 * net.nd
     _lib.call('cg_lrelu_bwd', _p(self.dh[0]), _p(self.h[0]), _p(self.dy[0]),
               self.B * nflat, LEAKY_ALPHA, st)
     _run_wgrad(self.b_in_wgrad, st)
     _lib.call('cg_colsum', _p(self.dy[0]), _p(G[1]), self.B, nflat, nflat, st)
+    # the conv-transpose weight gradients read h[i] / dy[i+1], which the chain
+    # above only produced: all of them together, at the end
+    _run_wgrads(self.b_wgrad, st)
 
 
 def adam_lr_t(step, lr, beta1=0.9, beta2=0.999):

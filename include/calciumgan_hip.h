@@ -183,6 +183,12 @@ typedef struct cg_wgrad_desc {
   long long bias_rows;
 } cg_wgrad_desc;
 int cg_wgrad(const cg_wgrad_desc* d, void* stream);
+/* n weight gradients (independent layers of one backward pass) as ONE launch
+ * when they are all the pipelined stride-2 form with the same tap count (the
+ * accumulator flush of one layer then overlaps the next layer's main loop);
+ * otherwise the same as n cg_wgrad calls.  Results as cg_wgrad (f32 atomics:
+ * the summation order differs). */
+int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream);
 
 /* ---------------------------------------------------------------------------
  * LayerNormalization(axis=-1, eps) + LeakyReLU, one wavefront per row.

@@ -620,3 +620,55 @@ def test_adam_colsum_sigmoid_lrelu_metrics():
   exp = [refm['signals_metrics/' + k].item() for k in ('min', 'max', 'mean',
                                                         'std')]
   np.testing.assert_allclose(got, exp, rtol=1e-4)
+
+
+def test_wgrad_batched_equals_individual_launches():
+  """cg_wgrad_batched (one launch over several layers) accumulates exactly
+  what the per-layer launches do; a batch that cannot be fused (a 1-tap Dense
+  gradient among them) falls back to individual launches."""
+  rng = np.random.RandomState(31)
+  layers = [(4, 512, 64, 128), (4, 256, 128, 192), (4, 128, 192, 64)]
+  k = 24
+  descs_a, descs_b, outs_a, outs_b, keep = [], [], [], [], []
+  for nB, L, Ci, Co in layers:
+    x = H.to_pitch(H.int_tensor(rng, (nB, L, Ci), -2, 2), geo.pitch(Ci))
+    g = H.to_pitch(H.int_tensor(rng, (nB, L // 2, Co), -2, 2), geo.pitch(Co))
+    sh = torch.tensor(rng.randint(-3, 4, size=2).astype(np.int32), device=H.DEV)
+    keep += [x, g, sh]
+    for descs, outs in ((descs_a, outs_a), (descs_b, outs_b)):
+      dw = torch.zeros(k, Ci, Co, dtype=torch.float32, device=H.DEV)
+      db = torch.zeros(Co, dtype=torch.float32, device=H.DEV)
+      d = nets._wgrad_desc(x, g, dw, nB, L, geo.pitch(Ci), L // 2,
+                           geo.pitch(Co), k, 2, -geo.same_padding_left(k, 2),
+                           Ci, Co, shifts=sh, seg_size=2, dbias=db,
+                           bias_rows=3 * (L // 2))
+      descs.append(d)
+      outs.append((dw, db))
+  for d in descs_a:
+    H.run_wgrad(d)
+  arr = (_lib.WgradDesc * len(descs_b))(*descs_b)
+  _lib.call('cg_wgrad_batched', arr, len(descs_b), H.stream())
+  H.sync()
+  for (dwa, dba), (dwb, dbb) in zip(outs_a, outs_b):
+    assert float(dwa.abs().max()) > 0
+    assert torch.equal(dwa, dwb) and torch.equal(dba, dbb)
+  # mixed batch: falls back, same results
+  B, L, Ci, Co = 2, 512, 102, 102
+  x = H.to_pitch(H.int_tensor(rng, (B, L, Ci), -2, 2), geo.pitch(Ci))
+  g = H.to_pitch(H.int_tensor(rng, (B, L, Co), -2, 2), geo.pitch(Co))
+  dws = [torch.zeros(1, Ci, Co, dtype=torch.float32, device=H.DEV)
+         for _ in range(2)]
+  dense = [nets._wgrad_desc(x, g, dw, B, L, geo.pitch(Ci), L, geo.pitch(Co), 1,
+                            1, 0, Ci, Co) for dw in dws]
+  H.run_wgrad(dense[0])
+  for dw, _ in outs_b:
+    dw.zero_()
+  mixed = [descs_b[0], dense[1], descs_b[1]]
+  arr = (_lib.WgradDesc * 3)(*mixed)
+  descs_b[0].dbias = None
+  descs_b[1].dbias = None
+  _lib.call('cg_wgrad_batched', arr, 3, H.stream())
+  H.sync()
+  assert torch.equal(dws[0], dws[1])
+  assert torch.equal(outs_b[0][0], outs_a[0][0])
+  assert torch.equal(outs_b[1][0], outs_a[1][0])
