@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("launch set: %s  (divided by %g recorded train() steps: warm-up + timed + the eager instrumented pass)" % (f.split('/')[-1], steps))
 print("total kernel ms/step %.2f" % (tot / 1e6 / steps))
-for fam in ("swconv_kernel", "wgrad_kernel"):
+for fam in ("swconv_kernel", "wgrad"):  # wgrad_kernel + wgrad_multi_kernel
     sel = [r for r in rows if fam in r["Name"]]
     calls = sum(int(r["Calls"]) for r in sel)
     ns = sum(float(r["TotalDurationNs"]) for r in sel)
