@@ -213,7 +213,11 @@ swconv_kernel(ConvArgs a) {
       tap = 0;
       q8l = UNI ? 0 : g;
     }
-    __syncthreads();  // previous part's fragment reads are done
+    // previous part's fragment reads are done (LDS only: a plain
+    // __syncthreads() would also wait vmcnt(0) and drain the weight DMAs that
+    // are in flight across this staging phase)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     // ---- stage the source window of this channel chunk ------------------
     if (a.nseg == 1) {
       // fast path (per-sample length >= tile): one sample per tile, no
@@ -322,7 +326,8 @@ swconv_kernel(ConvArgs a) {
         *reinterpret_cast<uint4*>(ldsA + row * a.pitchA + q8 * 8) = v;
       }
     }
-    __syncthreads();
+    // (no barrier here: the first weight stage below waits for this wave's
+    // window stores -- lgkmcnt(0) -- right before its own s_barrier)
 
     // Flattened K position inside the chunk: 16-byte group f = 4*kstep + g.
     // When 4 | c8 the four k-groups of a K-step share one tap and the walk is
@@ -340,6 +345,7 @@ swconv_kernel(ConvArgs a) {
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         else
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // window stores
         __builtin_amdgcn_s_barrier();
         if (gs + 2 < total_stages) issue_dma(gs + 2);
         const uint16_t* curB = ldsB + (gs % kNBufB) * kBufB;
