@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('CALCIUMGAN_HIP_LIB') or os.path.join(
     _HERE, 'csrc', 'libcalciumgan_hip.so')
 
 CG_EINVAL = 100001
-EPI_NONE, EPI_LRELU, EPI_MASK, EPI_SIGMOID = 0, 1, 2, 3
+EPI_NONE, EPI_LRELU, EPI_MASK, EPI_SIGMOID, EPI_LN_LRELU = 0, 1, 2, 3, 4
 # CG_TILE_*: value -> (rows, cols, mfma rows)
 TILES = {0: (256, 64, 16), 1: (64, 64, 16), 2: (128, 64, 16),
          3: (256, 64, 32), 4: (128, 64, 32), 5: (256, 128, 32),
@@ -43,6 +43,8 @@ class ConvDesc(C.Structure):
       ('rowsumsq', c_vp),
       ('w_parity_major', c_i),
       ('split_parity', c_i),
+      ('ln_gamma', c_vp), ('ln_beta', c_vp), ('ln_h', c_vp),
+      ('ln_mean', c_vp), ('ln_rstd', c_vp), ('ln_eps', c_f),
   ]
 
 

@@ -53,6 +53,13 @@ struct ConvArgs {
   int off_phase_step, yoff_phase_step;
   int gm, gn, gp;  // logical grid: row tiles, column tiles, phases
   int pmajor;      // stride 2: weights packed even taps first, then odd taps
+  // CG_EPI_LN_LRELU (128-column tiles, N <= 128)
+  const float* ln_gamma;
+  const float* ln_beta;
+  uint16_t* ln_h;
+  float* ln_mean;
+  float* ln_rstd;
+  float ln_eps;
 };
 
 // LDS row pitches, 16x16x32: 2*odd 16-byte slots: with the MFMA operand map
@@ -90,12 +97,14 @@ constexpr int kScratchBytes = 4 * 16 * kScrPitch * 4;
 // SP (stride 2, parity-major weights): the window of a channel chunk is staged
 // one source-row parity at a time -- half the LDS, so a 256-row stride-2 tile
 // leaves room for a third workgroup on the CU -- at twice the staging phases.
-template <int R, int MF, int WGN, int MT, int KS, bool UNI, bool SP = false>
+template <int R, int MF, int WGN, int MT, int KS, bool UNI, bool SP = false,
+          bool LN = false>
 __global__ __launch_bounds__(256, (MF == 32 && MT == 4)               ? 2
                                   : (MF == 16 && MT == 4 && KS == 2 && UNI) ? 3
                                                                      : 1) void
 swconv_kernel(ConvArgs a) {
   static_assert(!SP || (R == 2 && UNI), "split-parity staging is a stride-2 mode");
+  static_assert(!LN || WGN == 2, "the fused LayerNorm needs a 128-column tile");
   constexpr int NREG = SP ? 1 : R;  // parity regions resident in LDS at a time
   constexpr int NPART = SP ? 2 : 1; // staging parts per channel chunk
   // PIPE: all fragment reads of a weight stage are issued ahead of its MFMAs
@@ -429,8 +438,9 @@ swconv_kernel(ConvArgs a) {
   //   f32  out: columns cg*4 + {0..3} | 32 + same -> two 16-byte stores
   const int erow = lane >> 3;
   const int cg8 = lane & 7;
-  const int colA = a.out_f32 ? cg8 * 4 : cg8 * 8;
-  const int colB = a.out_f32 ? colA + 32 : colA + 4;
+  const bool of32 = !LN && a.out_f32;  // (the LayerNorm form stores bf16)
+  const int colA = of32 ? cg8 * 4 : cg8 * 8;
+  const int colB = of32 ? colA + 32 : colA + 4;
   const int nA = n0 + wn * 64 + colA;
   const int nB = n0 + wn * 64 + colB;
   float ssq = 0.f;  // sum of squares of this lane's outputs (rowsumsq)
@@ -439,6 +449,19 @@ swconv_kernel(ConvArgs a) {
   for (int e = 0; e < 4; ++e) {
     bv[e] = (a.bias && nA + e < a.N) ? a.bias[nA + e] : 0.f;
     bv[4 + e] = (a.bias && nB + e < a.N) ? a.bias[nB + e] : 0.f;
+  }
+  // fused LayerNorm + LeakyReLU (128-column tiles): the row statistics span
+  // the two waves that share a row block (wave ^ 1); their partial sums meet
+  // in a small LDS table behind the transpose scratch
+  float* part = reinterpret_cast<float*>(smem) + kScratchBytes / 4;
+  float* lnp = part + 4 * 16 * 2;  // gamma[128] | beta[128] (zero past N)
+  if constexpr (LN) {
+    if (tid < 128) {
+      // (kept in LDS rather than 16 registers per lane; first read after the
+      // first pass's workgroup barrier)
+      lnp[tid] = tid < a.N ? a.ln_gamma[tid] : 0.f;
+      lnp[128 + tid] = tid < a.N ? a.ln_beta[tid] : 0.f;
+    }
   }
   // 16 rows x 64 columns of the wave tile at a time
 #pragma unroll
@@ -468,7 +491,72 @@ swconv_kernel(ConvArgs a) {
     for (int pass = 0; pass < 2; ++pass) {
       const int row = pass * 8 + erow;
       const int m = m0 + (wm * MT + mt) * MF + h * 16 + row;
-      if (m < a.M && nA < a.Cy) {
+      if constexpr (LN) {
+        {
+          // (every lane takes part: the workgroup barrier below is uniform)
+          const f32x4 v0 =
+              *reinterpret_cast<const f32x4*>(scr + row * kScrPitch + colA);
+          const f32x4 v1 =
+              *reinterpret_cast<const f32x4*>(scr + row * kScrPitch + colB);
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int n = (e < 4 ? nA : nB - 4) + e;
+            // statistics of the STORED (bf16) pre-activation, as the separate
+            // cg_ln_lrelu_fwd pass sees it
+            v[e] = n < a.N ? bf2f(f2bf(v[e] + bv[e])) : 0.f;
+            s1 += v[e];
+            s2 += v[e] * v[e];
+          }
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+          }
+          if (cg8 == 0)
+            *reinterpret_cast<float2*>(part + (wave * 16 + row) * 2) =
+                make_float2(s1, s2);
+          __syncthreads();
+          const float2 o2 = *reinterpret_cast<const float2*>(
+              part + ((wave ^ 1) * 16 + row) * 2);
+          const float invn = 1.f / (float)a.N;
+          const float mean = (s1 + o2.x) * invn;
+          const float var = fmaxf((s2 + o2.y) * invn - mean * mean, 0.f);
+          const float rstd = rsqrtf(var + a.ln_eps);
+          if (m < a.M && nA < a.Cy) {
+            const int b = m / a.Lu;
+            const int u = m - b * a.Lu;
+            const long long ridx =
+                (long long)b * a.Ly + (long long)a.y_stride * u + y_off;
+            const long long rowoff = ridx * a.Cy;
+            const int lc = wn * 64 + colA;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(lnp + lc);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(lnp + lc + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(lnp + 128 + lc);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(lnp + 128 + lc + 4);
+            float hv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float t = (v[e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) +
+                              (e < 4 ? b0[e] : b1[e - 4]);
+              hv[e] = fmaxf(t, a.alpha * t);
+            }
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.y) + rowoff +
+                                      nA) =
+                make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
+                           pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            *reinterpret_cast<uint4*>(a.ln_h + rowoff + nA) =
+                make_uint4(pack2bf(hv[0], hv[1]), pack2bf(hv[2], hv[3]),
+                           pack2bf(hv[4], hv[5]), pack2bf(hv[6], hv[7]));
+            if (wn == 0 && cg8 == 0) {
+              a.ln_mean[ridx] = mean;
+              a.ln_rstd[ridx] = rstd;
+            }
+          }
+        }
+      }
+      if (!LN && m < a.M && nA < a.Cy) {
         const int b = m / a.Lu;
         const int u = m - b * a.Lu;
         const long long rowoff =
@@ -758,20 +846,22 @@ extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {
   CG_LAUNCH_CHECK();
 }
 
-template <int R, int MF, int WGN, int MT, int KS, bool UNI, bool SP = false>
+template <int R, int MF, int WGN, int MT, int KS, bool UNI, bool SP = false,
+          bool LN = false>
 static int launch_swconv1(const ConvArgs& a, dim3 grid, size_t lds,
                           hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
-            &swconv_kernel<R, MF, WGN, MT, KS, UNI, SP>),
+            &swconv_kernel<R, MF, WGN, MT, KS, UNI, SP, LN>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  CG_LAUNCH_PROF(CG_FAMILY_SWCONV, (swconv_kernel<R, MF, WGN, MT, KS, UNI, SP>),
-                 grid, dim3(256), lds, stream, a);
+  CG_LAUNCH_PROF(CG_FAMILY_SWCONV,
+                 (swconv_kernel<R, MF, WGN, MT, KS, UNI, SP, LN>), grid,
+                 dim3(256), lds, stream, a);
   CG_LAUNCH_CHECK();
 }
 
@@ -780,6 +870,15 @@ static int launch_swconv(const ConvArgs& a, dim3 grid, size_t lds, bool sp,
                          hipStream_t stream) {
   if constexpr (R == 2) {
     if (sp) return launch_swconv1<R, MF, WGN, MT, KS, true, true>(a, grid, lds, stream);
+  }
+  if (a.epilogue == CG_EPI_LN_LRELU) {
+    // Conv1DTranspose + LayerNorm: stride-1 phases on the 128-column tiles
+    if constexpr (R == 1 && MF == 32 && WGN == 2) {
+      if ((a.c8 & 3) == 0)
+        return launch_swconv1<R, MF, WGN, MT, KS, true, false, true>(a, grid, lds,
+                                                                    stream);
+    }
+    return CG_EINVAL;
   }
   if ((a.c8 & 3) == 0)
     return launch_swconv1<R, MF, WGN, MT, KS, true>(a, grid, lds, stream);
@@ -821,6 +920,10 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   const int R = d->stride;
   if (d->tile < 0 || d->tile >= CG_NUM_TILES) return CG_EINVAL;
   const TileCfg tc = kTileCfgs[d->tile];
+  if (d->epilogue == CG_EPI_LN_LRELU &&
+      (tc.wgn != 2 || d->N > 128 || d->out_f32 || d->rowsumsq || !d->ln_gamma ||
+       !d->ln_beta || !d->ln_h || !d->ln_mean || !d->ln_rstd))
+    return CG_EINVAL;
   const int TM = (4 / tc.wgn) * tc.mt * tc.mf;
   const int TN = 64 * tc.wgn;
   if (tc.mf == 32 && (d->CK / 8) % 4) return CG_EINVAL;  // uniform K walk only
@@ -864,6 +967,9 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   if (sp && (!a.pmajor || (a.c8 & 3) || (d->taps & 1))) return CG_EINVAL;
   a.ldsA_elems = (sp ? 1 : R) * a.nseg * a.WR * a.pitchA;
   a.epilogue = d->epilogue; a.out_f32 = d->out_f32; a.alpha = d->alpha;
+  a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta;
+  a.ln_h = reinterpret_cast<uint16_t*>(d->ln_h);
+  a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_eps = d->ln_eps;
   a.w_phase_stride = d->w_phase_stride;
   a.off_phase_step = d->off_phase_step;
   a.yoff_phase_step = d->yoff_phase_step;

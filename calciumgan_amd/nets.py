@@ -177,7 +177,7 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
                y_stride=1, y_off=0, bias=None, mask_src=None, shifts=None,
                seg_size=1, epilogue=_lib.EPI_NONE, out_f32=False, nphase=1,
                w_phase_stride=0, off_phase_step=0, yoff_phase_step=0,
-               rowsumsq=None, w_parity_major=False):
+               rowsumsq=None, w_parity_major=False, ln=None):
   d = ConvDesc()
   d.w_parity_major = int(bool(w_parity_major) and stride == 2)
   d.split_parity = 0
@@ -203,8 +203,28 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
   if small == 0 and stride == 2 and CK <= 32 and Lu % 128 == 0:
     small = 2
   d.tile = small
+  if ln is not None:
+    # LayerNorm + LeakyReLU in the producing launch (gamma, beta, h, mean,
+    # rstd): the row statistics need the whole row in one workgroup
+    d._keep = d._keep + tuple(ln)
+    d.epilogue = _lib.EPI_LN_LRELU
+    d.ln_gamma, d.ln_beta, d.ln_h, d.ln_mean, d.ln_rstd = (
+        t.data_ptr() for t in ln)
+    d.ln_eps = LN_EPS
+    d.tile = 6  # CG_TILE_128x128_M32
   _autotune_tile(d)
   return d
+
+
+# CALCIUMGAN_FUSE_LN=0 keeps LayerNorm a separate pass (A/B, debugging)
+_FUSE_LN = __import__('os').environ.get('CALCIUMGAN_FUSE_LN', '1') != '0'
+
+
+def _ln_fusable(lay, CK, taps):
+  """Conv1DTranspose + LayerNorm in one launch: rows of at most 128 channels
+  (one 128-column tile) on the 32x32x16 tiles (uniform 32-channel K walk)."""
+  return (_FUSE_LN and lay.cout <= 128 and CK % 32 == 0 and geo.lds_bytes(
+      CK, 1, taps, lay.lin, 128, 128, 32) <= geo.LDS_BYTES)
 
 
 # Tile / weight-stage choice by measurement: the best of the CG_TILE_* shapes x
@@ -262,7 +282,10 @@ def _autotune_tile(d):
         ok = False
       if mf == 32 and d.CK % 32:
         ok = False
-      if tn > 64 and d.N <= 64:
+      if d.epilogue == _lib.EPI_LN_LRELU:
+        if tn != 128:
+          ok = False
+      elif tn > 64 and d.N <= 64:
         ok = False
       if ok and geo.lds_bytes(d.CK, d.stride, d.taps, d.Lu, tm, tn,
                               mf) <= geo.LDS_BYTES:
@@ -721,9 +744,12 @@ class _GenWorkspace(object):
                            w0 * nd, 1, w0 * nd, net.w_in.CK, bias=V[1],
                            epilogue=_lib.EPI_LRELU)
     self.f_conv = []
+    self.ln_fused = []
     for i, (lay, ic) in enumerate(zip(net.layers, net.idx_conv)):
       op = net.w_fwd[i]
       dst = self.ypre[i + 1] if net.layer_norm else self.h[i + 1]
+      fuse = net.layer_norm and _ln_fusable(lay, op.CK, k // 2)
+      self.ln_fused.append(fuse)
       self.f_conv.append(
           _conv_desc(self.h[i], op.buf, dst, B, lay.lin, lay.cinp, k // 2, 1,
                      net.fwd_offs[0], lay.lin, lay.cout, lay.lout, lay.coutp,
@@ -732,7 +758,9 @@ class _GenWorkspace(object):
                      if net.layer_norm else _lib.EPI_LRELU, nphase=2,
                      w_phase_stride=op.elems,
                      off_phase_step=net.fwd_offs[1] - net.fwd_offs[0],
-                     yoff_phase_step=1))
+                     yoff_phase_step=1,
+                     ln=(V[ic + 2], V[ic + 3], self.h[i + 1], self.mean[i + 1],
+                         self.rstd[i + 1]) if fuse else None))
     self.f_out = _conv_desc(
         self.h[-1], net.w_out.buf, self.fake, B, net.L, net.Cp, 1, 1, 0, net.L,
         net.C, net.L, net.Cp, net.w_out.CK, bias=V[net.idx_out + 1],
@@ -769,7 +797,7 @@ class _GenWorkspace(object):
     V = net.params.views
     for i, (lay, ic) in enumerate(zip(net.layers, net.idx_conv)):
       _run_conv(self.f_conv[i], st)
-      if net.layer_norm:
+      if net.layer_norm and not self.ln_fused[i]:
         _lib.call('cg_ln_lrelu_fwd', _p(self.ypre[i + 1]), _p(V[ic + 2]),
                   _p(V[ic + 3]), _p(self.h[i + 1]), _p(self.mean[i + 1]),
                   _p(self.rstd[i + 1]), self.B * lay.lout, lay.cout, lay.coutp,

@@ -27,13 +27,14 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 3
+#define CG_ABI_VERSION 4
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
 #define CG_EPI_LRELU 1    /* y = leaky_relu(acc + bias, alpha) */
 #define CG_EPI_MASK 2     /* y = acc * (mask_src > 0 ? 1 : alpha) */
 #define CG_EPI_SIGMOID 3  /* y = sigmoid(acc + bias) */
+#define CG_EPI_LN_LRELU 4 /* y = acc + bias; ln_h = leaky_relu(layernorm(y)) */
 
 /* workgroup tile of cg_swconv (rows x columns of y per workgroup); the _M32
  * tiles run v_mfma_f32_32x32x16_bf16 and need CK % 32 == 0, the others
@@ -110,6 +111,17 @@ typedef struct cg_conv_desc {
   int split_parity;     /* stride 2 + w_parity_major: stage one source-row
                            parity at a time (half the LDS window, twice the
                            staging phases; results identical) */
+  /* CG_EPI_LN_LRELU only (layers.LayerNormalization + LeakyReLU after
+   * Conv1DTranspose, calciumgan.py:68-70 fused into the producing launch):
+   * y receives the bf16 pre-activation, ln_h = lrelu(LN(y)), ln_mean / ln_rstd
+   * the per-row statistics (indexed like rows of y) cg_ln_lrelu_bwd consumes.
+   * Needs N <= 128, bf16 output and a 128-column tile (cg_tile_shape). */
+  const float* ln_gamma; /* f32 [N] */
+  const float* ln_beta;  /* f32 [N] */
+  void* ln_h;            /* bf16, geometry of y */
+  float* ln_mean;        /* f32 [nB*Ly] */
+  float* ln_rstd;        /* f32 [nB*Ly] */
+  float ln_eps;
 } cg_conv_desc;
 
 int cg_swconv(const cg_conv_desc* d, void* stream);

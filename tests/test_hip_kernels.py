@@ -244,6 +244,73 @@ def test_conv_transpose_fwd_bitexact(B, L, Ci, Co, k):
   np.testing.assert_array_equal(y.cpu()[:, :, :Co].numpy(), ref.numpy())
 
 
+@pytest.mark.parametrize('tile,ks', [(5, 2), (5, 4), (6, 2), (6, 4)])
+@pytest.mark.parametrize('B,L,Ci,Co,k', [(3, 256, 128, 102, 24),
+                                          (2, 512, 192, 128, 24),
+                                          (5, 16, 64, 40, 24),
+                                          (2, 4, 32, 6, 8)])
+def test_conv_transpose_layernorm_fused(tile, ks, B, L, Ci, Co, k):
+  """Conv1DTranspose + LayerNormalization + LeakyReLU (calciumgan.py:61-70) in
+  one launch == the same launch without the fusion followed by the separate
+  cg_ln_lrelu_fwd pass: the stored pre-activation bit for bit, the statistics
+  and the activation to rounding."""
+  tm = _lib.TILES[tile][0]
+  if not ((L % tm == 0) if L >= tm else (tm % L == 0)):
+    pytest.skip('row tile does not divide this length')
+  rng = np.random.RandomState(21)
+  x = torch.tensor(rng.randn(B, L, Ci).astype(np.float32))
+  Wt = torch.tensor(rng.randn(k, 1, Co, Ci).astype(np.float32) * 0.05)
+  b = torch.tensor(rng.randn(Co).astype(np.float32) * 0.2)
+  gam = torch.tensor(rng.rand(Co).astype(np.float32) + 0.5).to(H.DEV)
+  bet = torch.tensor(rng.randn(Co).astype(np.float32) * 0.1).to(H.DEV)
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  pl = geo.same_padding_left(k, 2)
+  phases = nets._transpose_phases(k, pl)
+  offs = [o for _, o in phases]
+  ck = nets._ck_for(cip, 1, k // 2, L)
+  op = H.pack(Wt.to(H.DEV), [(t0, -2, Co * Ci, 1, Ci) for t0, _ in phases], Ci,
+              Co, cip, ck, k // 2)
+  rows = B * 2 * L
+  xd = H.to_pitch(x, cip)
+  z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=H.DEV)
+  y0, h0 = z(B, 2 * L, cop), z(B, 2 * L, cop)
+  m0, r0 = z(rows, dt=torch.float32), z(rows, dt=torch.float32)
+  y1, h1 = z(B, 2 * L, cop), z(B, 2 * L, cop)
+  m1, r1 = z(rows, dt=torch.float32), z(rows, dt=torch.float32)
+  common = dict(y_stride=2, bias=b.to(H.DEV), nphase=2, w_phase_stride=op.elems,
+                off_phase_step=offs[1] - offs[0], yoff_phase_step=1)
+  d0 = H.conv_desc(xd, op.buf, y0, B, L, cip, k // 2, 1, offs[0], L, Co, 2 * L,
+                   cop, ck, **common)
+  H.run_conv(d0)
+  _lib.call('cg_ln_lrelu_fwd', H.p(y0), H.p(gam), H.p(bet), H.p(h0), H.p(m0),
+            H.p(r0), rows, Co, cop, 1e-3, ALPHA, H.stream())
+  d1 = H.conv_desc(xd, op.buf, y1, B, L, cip, k // 2, 1, offs[0], L, Co, 2 * L,
+                   cop, ck, ln=(gam, bet, h1, m1, r1), **common)
+  d1.tile, d1.stage_ksteps = tile, ks
+  H.run_conv(d1)
+  H.sync()
+  # the MFMA shapes of d0's tile and the 32x32x16 tiles may differ in the last
+  # f32 bit of a partial sum -> at most one bf16 ulp on a rounding tie
+  ya, yb = y0.float().cpu().numpy(), y1.float().cpu().numpy()
+  np.testing.assert_allclose(yb, ya, rtol=2 ** -7, atol=1e-6)
+  assert np.mean(ya != yb) < 1e-3
+  np.testing.assert_allclose(m1.cpu().numpy(), m0.cpu().numpy(), rtol=1e-4,
+                             atol=2e-4)
+  np.testing.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=2e-4)
+  ha, hb = h0.float().cpu().numpy(), h1.float().cpu().numpy()
+  np.testing.assert_allclose(hb, ha, rtol=2 ** -6, atol=2e-3)
+  assert np.mean(ha != hb) < 2e-2
+  if cop > Co:
+    assert float(y1[:, :, Co:].float().abs().max()) == 0.0
+    assert float(h1[:, :, Co:].float().abs().max()) == 0.0
+  # and against the f64 oracle of the three reference layers
+  ref = O.leaky_relu(O.layer_norm(
+      O.conv1d_transpose_same(x.to(BF16).double(), Wt.to(BF16).double(),
+                              b.double(), 2),
+      gam.cpu().double(), bet.cpu().double()))
+  np.testing.assert_allclose(hb[:, :, :Co], ref.numpy(), rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize('B,L,Ci,Co,k', [(2, 64, 32, 320, 24),
                                           (3, 128, 128, 102, 24)])
 def test_conv_transpose_dgrad_bitexact(B, L, Ci, Co, k):
