@@ -71,6 +71,8 @@ class WgradDesc(C.Structure):
       ('tile_rows', c_i),
       ('dbias', c_vp),
       ('bias_rows', c_ll),
+      ('partials', c_vp),
+      ('partials_elems', c_ll),
   ]
 
 
@@ -89,6 +91,7 @@ SIGNATURES = {
     'cg_pack_batched': [c_vp, c_i, c_ll, c_vp],
     'cg_wgrad': [C.POINTER(WgradDesc), c_vp],
     'cg_wgrad_batched': [C.POINTER(WgradDesc), c_i, c_vp],
+    'cg_wgrad_partials_elems': [C.POINTER(WgradDesc)],
     'cg_ln_lrelu_fwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_f,
                         c_f, c_vp],
     'cg_ln_lrelu_bwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -117,7 +120,7 @@ SIGNATURES = {
                           c_vp],
 }
 _RESTYPES = {'cg_packed_elems': c_ll, 'cg_pack_plan_bytes': c_ll,
-             'cg_pack_plan_build': c_ll}
+             'cg_pack_plan_build': c_ll, 'cg_wgrad_partials_elems': c_ll}
 
 _lib = None
 

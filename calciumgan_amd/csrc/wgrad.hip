@@ -33,6 +33,10 @@ struct WgradArgs {
   int ntiles;
   float* dbias;
   long long bias_rows;
+  // K'-split partial sums as plain stores (reduced by wgrad_reduce_kernel)
+  // instead of f32 atomics into dw; null: atomics
+  float* part;
+  int pgx, pgy;  // (cx, cg) block grid of the launch
 };
 
 constexpr int kPitchX = 48;  // 32 ch + 16 pad  (96 B = 32*3)
@@ -366,6 +370,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
     if (tid < 64 && cg0 + tid < a.Cg_real) atomicAdd(a.dbias + cg0 + tid, red[tid]);
   }
 
+  if (!ROWSPLIT && a.part) {
+    // accumulators in register order: every store instruction of a wave is one
+    // contiguous 1 KiB run; block (bz, by, bx), slot (s, mt, nt), thread
+    float* pb = a.part + ((long long)(bz * a.pgy + by) * a.pgx + bx) *
+                             (TPW * 8 * 2048) + tid * 4;
+#pragma unroll
+    for (int s = 0; s < TPW; ++s)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          *reinterpret_cast<f32x4*>(pb + ((s * 2 + mt) * 4 + nt) * 2048) =
+              acc[s][mt][nt];
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < TPW; ++s) {
     const int tap = ROWSPLIT ? 0 : wave + 8 * s;
@@ -389,6 +408,58 @@ template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, bool ALLT>
 __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   wgrad_body<R, TPW, ROWSPLIT, PIPE, TT, ALLT>(a, blockIdx.x, blockIdx.y,
                                                blockIdx.z, gridDim.z);
+}
+
+// Second stage of the partial-sum path: thread (block tile, slot, tid) sums its
+// float4 over the K' splits (each read one contiguous 4 KiB run per wave-instruction
+// pair) and adds the result into dw.  One thread owns an element: no atomics.
+struct ReduceItem {
+  const float* part;
+  float* dw;
+  int gx, gy, gz, tpw, taps, Cx_real, Cg_real;
+};
+struct ReduceArgs {
+  int n;
+  ReduceItem it[6];
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceArgs ra) {
+  const ReduceItem& it = ra.it[blockIdx.y];
+  const int per_tile = it.tpw * 8 * 512;  // float4 per block tile
+  const long long total = (long long)it.gx * it.gy * per_tile;
+  const long long blk_stride = (long long)it.gx * it.gy * per_tile * 4;  // floats per split
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (long long)gridDim.x * 256) {
+    const int tile = (int)(e / per_tile);
+    const int rem = (int)(e - (long long)tile * per_tile);
+    const int slot = rem >> 9;
+    const int tid = rem & 511;
+    const float* p = it.part + (long long)tile * per_tile * 4 + rem * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 4 <= it.gz; z += 4) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (z + 0) * blk_stride);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (z + 1) * blk_stride);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (z + 2) * blk_stride);
+      const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (z + 3) * blk_stride);
+      sum += (v0 + v1) + (v2 + v3);
+    }
+    for (; z < it.gz; ++z)
+      sum += *reinterpret_cast<const f32x4*>(p + z * blk_stride);
+    const int bx = tile % it.gx, by = tile / it.gx;
+    const int s = slot >> 3, mt = (slot >> 2) & 1, nt = slot & 3;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int tap = wave + 8 * s;
+    const int cg = by * 64 + nt * 16 + (lane & 15);
+    if (tap < it.taps && cg < it.Cg_real) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cx = bx * 32 + mt * 16 + 4 * (lane >> 4) + r;
+        if (cx < it.Cx_real)
+          it.dw[((long long)tap * it.Cx_real + cx) * it.Cg_real + cg] += sum[r];
+      }
+    }
+  }
 }
 
 // Several layers' weight gradients in ONE launch: workgroup b does item b of
@@ -471,6 +542,7 @@ namespace {
 struct WgradPlan {
   WgradArgs a;
   int gx, gy, nsplit, TT, R, tpw;
+  long long part_elems;
   size_t lds;
   bool pipe, rowsplit;
 };
@@ -533,7 +605,35 @@ int plan_wgrad(const cg_wgrad_desc* d, WgradPlan& p) {
   p.nsplit = nsplit;
   p.TT = TT; p.R = R; p.lds = lds; p.rowsplit = rowsplit;
   p.tpw = rowsplit ? 1 : (d->taps <= 8 ? 1 : (d->taps <= 16 ? 2 : 3));
+  a.part = nullptr;
+  a.pgx = p.gx; a.pgy = p.gy;
+  p.part_elems = (rowsplit || nsplit < 2)
+                     ? 0
+                     : (long long)p.gx * p.gy * nsplit * p.tpw * 8 * 2048;
+  if (d->partials && p.part_elems > 0) {
+    if (d->partials_elems < p.part_elems) return CG_EINVAL;
+    a.part = d->partials;
+  }
   return 0;
+}
+
+void reduce_item(const WgradPlan& p, ReduceItem& it) {
+  it.part = p.a.part; it.dw = p.a.dw;
+  it.gx = p.gx; it.gy = p.gy; it.gz = p.nsplit; it.tpw = p.tpw;
+  it.taps = p.a.taps; it.Cx_real = p.a.Cx_real; it.Cg_real = p.a.Cg_real;
+}
+
+int launch_reduce(const ReduceArgs& ra, hipStream_t s) {
+  long long most = 0;
+  for (int i = 0; i < ra.n; ++i) {
+    const long long t = (long long)ra.it[i].gx * ra.it[i].gy * ra.it[i].tpw * 8 * 512;
+    if (t > most) most = t;
+  }
+  long long bx = (most + 255) / 256;
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)bx, ra.n), dim3(256), 0, s,
+                     ra);
+  CG_LAUNCH_CHECK();
 }
 
 int launch_plan(const WgradPlan& p, hipStream_t s) {
@@ -566,9 +666,23 @@ int launch_multi(const WgradMulti& m, int blocks, size_t lds, hipStream_t s) {
 
 extern "C" int cg_wgrad(const cg_wgrad_desc* d, void* stream) {
   WgradPlan p;
-  const int rc = plan_wgrad(d, p);
+  int rc = plan_wgrad(d, p);
   if (rc) return rc;
-  return launch_plan(p, (hipStream_t)stream);
+  rc = launch_plan(p, (hipStream_t)stream);
+  if (rc || !p.a.part) return rc;
+  ReduceArgs ra;
+  ra.n = 1;
+  reduce_item(p, ra.it[0]);
+  return launch_reduce(ra, (hipStream_t)stream);
+}
+
+extern "C" long long cg_wgrad_partials_elems(const cg_wgrad_desc* d) {
+  if (!d) return -1;
+  cg_wgrad_desc c = *d;
+  c.partials = nullptr;
+  WgradPlan p;
+  const int rc = plan_wgrad(&c, p);
+  return rc ? -1 : p.part_elems;
 }
 
 extern "C" int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream) {
@@ -605,9 +719,16 @@ extern "C" int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream)
     if (nb > blocks) blocks = nb;
     if (2 * p.lds > lds) lds = 2 * p.lds;
   }
+  int rc;
   switch (plans[0].tpw) {
-    case 1: return launch_multi<1>(m, blocks, lds, s);
-    case 2: return launch_multi<2>(m, blocks, lds, s);
-    default: return launch_multi<3>(m, blocks, lds, s);
+    case 1: rc = launch_multi<1>(m, blocks, lds, s); break;
+    case 2: rc = launch_multi<2>(m, blocks, lds, s); break;
+    default: rc = launch_multi<3>(m, blocks, lds, s); break;
   }
+  if (rc) return rc;
+  ReduceArgs ra;
+  ra.n = 0;
+  for (int i = 0; i < n; ++i)
+    if (plans[i].a.part) reduce_item(plans[i], ra.it[ra.n++]);
+  return ra.n ? launch_reduce(ra, s) : 0;
 }

@@ -330,8 +330,18 @@ def _autotune_tile(d):
   d.tile, d.stage_ksteps, d.split_parity = best
 
 
+# K'-split partial sums of cg_wgrad: plain stores + a reducing launch instead of
+# f32 atomics (CALCIUMGAN_WGRAD_PARTIALS=0: atomics).  Workspaces are shared by
+# the descriptors of one slot (= position in a batched launch): launches are
+# stream-ordered, so a slot's buffer is free again when the next batch starts.
+_WGRAD_PARTIALS = __import__('os').environ.get('CALCIUMGAN_WGRAD_PARTIALS',
+                                                '1') != '0'
+_PARTIALS_POOL = {}
+
+
 def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,
-                Cg_real, shifts=None, seg_size=1, dbias=None, bias_rows=0):
+                Cg_real, shifts=None, seg_size=1, dbias=None, bias_rows=0,
+                slot=None):
   d = WgradDesc()
   d._keep = (x, g, dw, shifts, dbias)  # pointers below borrow these
   d.dbias = dbias.data_ptr() if dbias is not None else None
@@ -343,6 +353,15 @@ def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,
   d.taps, d.stride, d.off = taps, stride, off
   d.Cx_real, d.Cg_real = Cx_real, Cg_real
   d.nsplit = 0
+  if slot is not None and _WGRAD_PARTIALS and x.is_cuda:
+    need = _lib.load().cg_wgrad_partials_elems(ctypes.byref(d))
+    if need > 0:
+      buf = _PARTIALS_POOL.get((slot, need))
+      if buf is None:
+        buf = torch.empty(need, dtype=torch.float32, device=x.device)
+        _PARTIALS_POOL[(slot, need)] = buf
+      d._keep = d._keep + (buf,)
+      d.partials, d.partials_elems = buf.data_ptr(), need
   return d
 
 
@@ -524,7 +543,7 @@ class _DisPlan(object):
           _wgrad_desc(ws.act[i], ws.delta[i + 1], net.params.grad_views[2 * i],
                       nB, lay.lin, lay.cinp, lay.lout, lay.coutp, k, 2, -pl,
                       lay.cin, lay.cout, shifts=sh, seg_size=seg_size,
-                      dbias=net.params.grad_views[2 * i + 1]))
+                      dbias=net.params.grad_views[2 * i + 1], slot=i))
     # input-gradient chain: layer i (1-based l = i+1) maps delta[l] -> e[l-1]
     for i in range(len(net.layers) - 1, 0, -1):
       lay = net.layers[i]
@@ -783,7 +802,8 @@ class _GenWorkspace(object):
                      w_parity_major=op.parity_major))
       self.b_wgrad.append(
           _wgrad_desc(self.dy[i + 1], self.h[i], G[ic], B, lay.lout, lay.coutp,
-                      lay.lin, lay.cinp, k, 2, -net.pl, lay.cout, lay.cin))
+                      lay.lin, lay.cinp, k, 2, -net.pl, lay.cout, lay.cin,
+                      slot=i))
     self.b_in_wgrad = _wgrad_desc(self.z, self.dy[0], G[0], B, 1, nd, 1,
                                   w0 * nd, 1, 1, 0, nd, w0 * nd)
 

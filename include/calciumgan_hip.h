@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 4
+#define CG_ABI_VERSION 5
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -193,13 +193,23 @@ typedef struct cg_wgrad_desc {
                         bias_rows (b,u) rows -- the conv bias gradient, taken
                         from the g tiles already staged in LDS */
   long long bias_rows;
+  float* partials;   /* optional workspace of >= cg_wgrad_partials_elems(d) f32:
+                        the K' splits then leave their partial sums with plain
+                        stores and a second kernel adds them into dw (one owner
+                        per element: deterministic), instead of every split
+                        adding into dw with f32 atomics.  NULL: atomics. */
+  long long partials_elems;
 } cg_wgrad_desc;
 int cg_wgrad(const cg_wgrad_desc* d, void* stream);
+/* f32 elements of `partials` this descriptor needs (0: the launch has a single
+ * K' split or is the taps == 1 form, which always uses atomics); < 0: error */
+long long cg_wgrad_partials_elems(const cg_wgrad_desc* d);
 /* n weight gradients (independent layers of one backward pass) as ONE launch
  * when they are all the pipelined stride-2 form with the same tap count (the
  * accumulator flush of one layer then overlaps the next layer's main loop);
  * otherwise the same as n cg_wgrad calls.  Results as cg_wgrad (f32 atomics:
- * the summation order differs). */
+ * the summation order differs); descriptors with `partials` are reduced by one
+ * extra launch for all layers. */
 int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -86,10 +86,11 @@ def test_conv_dgrad_wgrad_are_adjoint_at_full_size(nB, L, Ci, Co, k, seg):
                    yoff_phase_step=1)
   H.run_conv(dd)
 
-  # dW = wgrad(S x, g), f32 atomics over the K' splits
+  # dW = wgrad(S x, g): K'-split partial sums + reducing launch (the product
+  # path's form)
   dw = torch.zeros(k, Ci, Co, dtype=torch.float32, device=H.DEV)
   dwd = nets._wgrad_desc(xd, gd, dw, nB, L, cip, Lo, cop, k, 2, -pl, Ci, Co,
-                         shifts=sh, seg_size=seg)
+                         shifts=sh, seg_size=seg, slot=0)
   H.run_wgrad(dwd)
   H.sync()
 

@@ -400,8 +400,11 @@ WGRAD_CASES = [
 ]
 
 
+@pytest.mark.parametrize('partials', [False, True])
 @pytest.mark.parametrize('nB,L,Ci,Co,k,seg,use_shift', WGRAD_CASES)
-def test_conv_wgrad_bitexact(nB, L, Ci, Co, k, seg, use_shift):
+def test_conv_wgrad_bitexact(nB, L, Ci, Co, k, seg, use_shift, partials):
+  """partials = True: the K' splits store partial sums that a second launch
+  adds into dw (which must ACCUMULATE: dw starts at 1); False: f32 atomics."""
   rng = np.random.RandomState(7)
   x = H.int_tensor(rng, (nB, L, Ci), -2, 2)
   dy = H.int_tensor(rng, (nB, L // 2, Co), -2, 2)
@@ -413,17 +416,25 @@ def test_conv_wgrad_bitexact(nB, L, Ci, Co, k, seg, use_shift):
   (O.conv1d_same(_shuffle_batch(x, shifts, seg), W, None, 2) *
    dy).sum().backward()
   cip, cop = geo.pitch(Ci), geo.pitch(Co)
-  dw = torch.zeros(k, Ci, Co, dtype=torch.float32, device=H.DEV)
+  dw = torch.ones(k, Ci, Co, dtype=torch.float32, device=H.DEV)
   sh = torch.tensor(shifts, device=H.DEV)
   dbias = torch.zeros(Co, dtype=torch.float32, device=H.DEV)
   nb_bias = max(1, (2 * nB) // 3)  # bias gradient over the first samples only
   d = nets._wgrad_desc(H.to_pitch(x, cip), H.to_pitch(dy, cop), dw, nB, L, cip,
                        L // 2, cop, k, 2, -geo.same_padding_left(k, 2), Ci, Co,
                        shifts=sh if use_shift else None, seg_size=seg,
-                       dbias=dbias, bias_rows=nb_bias * (L // 2))
+                       dbias=dbias, bias_rows=nb_bias * (L // 2),
+                       slot=0 if partials else None)
+  if partials:
+    d.nsplit = 3  # several K' splits whatever the shape
+    need = _lib.load().cg_wgrad_partials_elems(ctypes.byref(d))
+    if need <= 0:
+      pytest.skip('single K\' split at this shape')
+    ws = torch.full((need,), float('nan'), device=H.DEV)
+    d.partials, d.partials_elems = ws.data_ptr(), need
   H.run_wgrad(d)
   H.sync()
-  np.testing.assert_array_equal(dw.cpu().numpy(), W.grad.numpy())
+  np.testing.assert_array_equal(dw.cpu().numpy(), W.grad.numpy() + 1.0)
   np.testing.assert_array_equal(dbias.cpu().numpy(),
                                 dy[:nb_bias].sum((0, 1)).numpy())
 
@@ -708,7 +719,8 @@ def test_wgrad_batched_equals_individual_launches():
       d = nets._wgrad_desc(x, g, dw, nB, L, geo.pitch(Ci), L // 2,
                            geo.pitch(Co), k, 2, -geo.same_padding_left(k, 2),
                            Ci, Co, shifts=sh, seg_size=2, dbias=db,
-                           bias_rows=3 * (L // 2))
+                           bias_rows=3 * (L // 2),
+                           slot=len(descs) if descs is descs_b else None)
       descs.append(d)
       outs.append((dw, db))
   for d in descs_a:
