@@ -99,7 +99,7 @@ constexpr int kScratchBytes = 4 * 16 * kScrPitch * 4;
 // leaves room for a third workgroup on the CU -- at twice the staging phases.
 template <int R, int MF, int WGN, int MT, int KS, bool UNI, bool SP = false,
           bool LN = false>
-__global__ __launch_bounds__(256, (MF == 32 && MT == 4)               ? 2
+__global__ __launch_bounds__(256, ((MF == 32 && MT == 4) || MT == 8)    ? 2
                                   : (MF == 16 && MT == 4 && KS == 2 && UNI) ? 3
                                                                      : 1) void
 swconv_kernel(ConvArgs a) {
@@ -873,7 +873,8 @@ static int launch_swconv(const ConvArgs& a, dim3 grid, size_t lds, bool sp,
   }
   if (a.epilogue == CG_EPI_LN_LRELU) {
     // Conv1DTranspose + LayerNorm: stride-1 phases on the 128-column tiles
-    if constexpr (R == 1 && MF == 32 && WGN == 2) {
+    // (uniform 32-channel K walk)
+    if constexpr (R == 1 && WGN == 2) {
       if ((a.c8 & 3) == 0)
         return launch_swconv1<R, MF, WGN, MT, KS, true, false, true>(a, grid, lds,
                                                                     stream);
@@ -897,6 +898,7 @@ static const TileCfg kTileCfgs[CG_NUM_TILES] = {
     {32, 1, 1},  // CG_TILE_128x64_M32
     {32, 2, 4},  // CG_TILE_256x128_M32
     {32, 2, 2},  // CG_TILE_128x128_M32
+    {16, 2, 8},  // CG_TILE_256x128
 };
 
 extern "C" int cg_tile_shape(int tile, int* rows, int* cols) {
@@ -1004,7 +1006,7 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   CG_DISPATCH(1, FF, WW, MM, 2) CG_DISPATCH(2, FF, WW, MM, 2)
   CG_DISPATCH_RK(16, 1, 4) CG_DISPATCH_RK(16, 1, 1) CG_DISPATCH_RK(16, 1, 2)
   CG_DISPATCH_RK(32, 1, 2) CG_DISPATCH_RK(32, 1, 1)
-  CG_DISPATCH_RK(32, 2, 4) CG_DISPATCH_RK(32, 2, 2)
+  CG_DISPATCH_RK(32, 2, 4) CG_DISPATCH_RK(32, 2, 2) CG_DISPATCH_RK(16, 2, 8)
 #undef CG_DISPATCH_RK
 #undef CG_DISPATCH
   return CG_EINVAL;

@@ -47,7 +47,8 @@ extern "C" {
 #define CG_TILE_128x64_M32 4
 #define CG_TILE_256x128_M32 5
 #define CG_TILE_128x128_M32 6
-#define CG_NUM_TILES 7
+#define CG_TILE_256x128 7
+#define CG_NUM_TILES 8
 
 int cg_abi_version(void);
 /* rows / columns of a CG_TILE_* value (host helper; CG_EINVAL if unknown) */
