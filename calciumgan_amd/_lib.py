@@ -45,6 +45,8 @@ class ConvDesc(C.Structure):
       ('split_parity', c_i),
       ('ln_gamma', c_vp), ('ln_beta', c_vp), ('ln_h', c_vp),
       ('ln_mean', c_vp), ('ln_rstd', c_vp), ('ln_eps', c_f),
+      ('out_shifts', c_vp), ('out_seg_size', c_i), ('side', c_vp),
+      ('side_rows', c_i),
   ]
 
 
@@ -103,6 +105,8 @@ SIGNATURES = {
                         c_vp],
     'cg_unshuffle_mask': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f,
                           c_vp],
+    'cg_unshuffle_fixup': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f,
+                           c_vp],
     'cg_interp_pack': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_vp],
     'cg_cast_pad': [c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],

@@ -408,6 +408,40 @@ __global__ __launch_bounds__(kThreads) void unshuffle_mask_kernel(
   store8(delta + rowg * Cp + c, acc);
 }
 
+// Second half of the unshuffle fused into the producing convolution
+// (cg_conv_desc.out_shifts): thread (b, j, 8 channels), j < |s|, zeroes the
+// row nothing maps to and folds reflected row j into its source row.
+__global__ __launch_bounds__(kThreads) void unshuffle_fixup_kernel(
+    const uint16_t* __restrict__ side, const uint16_t* __restrict__ h,
+    uint16_t* __restrict__ delta, const int* __restrict__ shifts, int w, int Cp,
+    int seg_size, int side_rows, float alpha, long long total8) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
+  const int per_row = Cp / 8;
+  const long long rowg = idx / per_row;
+  const int c = (int)(idx - rowg * per_row) * 8;
+  const int b = (int)(rowg / side_rows);
+  const int j = (int)(rowg - (long long)b * side_rows);
+  const int s = shifts[b / seg_size];
+  const int n = s > 0 ? s : -s;
+  if (j >= n) return;
+  // s > 0: reflected output row t = w - s + j came from r = w - 2 - j, rows
+  // [0, s) receive nothing; s < 0 (a = -s): t = j came from r = a - j, rows
+  // [w - a, w) receive nothing
+  const int r_add = s > 0 ? w - 2 - j : n - j;
+  const int r_zero = s > 0 ? j : w - n + j;
+  const long long base = (long long)b * w;
+  float sv[8], hv[8], dv[8];
+  load8(side + rowg * Cp + c, sv);
+  load8(h + (base + r_add) * Cp + c, hv);
+  load8(delta + (base + r_add) * Cp + c, dv);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dv[k] += sv[k] * (hv[k] > 0.f ? 1.f : alpha);
+  store8(delta + (base + r_add) * Cp + c, dv);
+  const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  store8(delta + (base + r_zero) * Cp + c, z);
+}
+
 // ---------------------------------------------------------------------------
 // WGAN-GP pieces
 // ---------------------------------------------------------------------------
@@ -797,6 +831,21 @@ extern "C" int cg_unshuffle_mask(const void* e, const void* h, void* delta,
                      dim3(grid1d(total8, kThreads, 1LL << 31)), dim3(kThreads),
                      0, S_(stream), U16(e), U16(h), U16W(delta), shifts, w, Cp,
                      seg_size, alpha, total8);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_unshuffle_fixup(const void* side, const void* h, void* delta,
+                                  const int* shifts, int nB, int w, int Cp,
+                                  int seg_size, int side_rows, float alpha,
+                                  void* stream) {
+  if (Cp % 8 || nB < 1 || w < 1 || seg_size < 1 || side_rows < 1 || !shifts ||
+      2 * side_rows + 1 > w)
+    return CG_EINVAL;
+  const long long total8 = (long long)nB * side_rows * Cp / 8;
+  hipLaunchKernelGGL(unshuffle_fixup_kernel,
+                     dim3(grid1d(total8, kThreads, 1LL << 31)), dim3(kThreads),
+                     0, S_(stream), U16(side), U16(h), U16W(delta), shifts, w,
+                     Cp, seg_size, side_rows, alpha, total8);
   CG_LAUNCH_CHECK();
 }
 

@@ -60,6 +60,11 @@ struct ConvArgs {
   float* ln_mean;
   float* ln_rstd;
   float ln_eps;
+  // output-side phase-shuffle adjoint (see cg_conv_desc.out_shifts)
+  const int* out_shifts;
+  int out_seg;
+  uint16_t* side;
+  int side_rows;
 };
 
 // LDS row pitches, 16x16x32: 2*odd 16-byte slots: with the MFMA operand map
@@ -559,8 +564,20 @@ swconv_kernel(ConvArgs a) {
       if (!LN && m < a.M && nA < a.Cy) {
         const int b = m / a.Lu;
         const int u = m - b * a.Lu;
+        int t = a.y_stride * u + y_off;
+        bool to_side = false;  // reflected-branch row of the unshuffle
+        if (a.out_shifts) {
+          const int s = a.out_shifts[b / a.out_seg];
+          if (s > 0) {
+            to_side = t >= a.Ly - s;
+            t = to_side ? t - (a.Ly - s) : t + s;
+          } else {
+            to_side = t < -s;
+            t = to_side ? t : t + s;
+          }
+        }
         const long long rowoff =
-            ((long long)b * a.Ly + (long long)a.y_stride * u + y_off) * a.Cy;
+            ((long long)b * (to_side ? a.side_rows : a.Ly) + t) * a.Cy;
         const f32x4 v0 =
             *reinterpret_cast<const f32x4*>(scr + row * kScrPitch + colA);
         const f32x4 v1 =
@@ -572,7 +589,12 @@ swconv_kernel(ConvArgs a) {
         if (a.epilogue == CG_EPI_LRELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], a.alpha * v[e]);
-        } else if (a.epilogue == CG_EPI_MASK) {
+        } else if (a.epilogue == CG_EPI_MASK && !to_side) {
+          if (a.out_shifts) {
+            // the unfused form stores this gradient in bf16 before masking
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+          }
           const uint2 ha = *reinterpret_cast<const uint2*>(a.mask + rowoff + nA);
           const uint2 hb = okB ? *reinterpret_cast<const uint2*>(a.mask + rowoff + nB)
                                : make_uint2(0u, 0u);
@@ -602,7 +624,8 @@ swconv_kernel(ConvArgs a) {
           if (okB)
             *reinterpret_cast<f32x4*>(dst + nB) = f32x4{v[4], v[5], v[6], v[7]};
         } else {
-          uint16_t* dst = reinterpret_cast<uint16_t*>(a.y) + rowoff + nA;
+          uint16_t* dst =
+              (to_side ? a.side : reinterpret_cast<uint16_t*>(a.y)) + rowoff + nA;
           *reinterpret_cast<uint4*>(dst) =
               make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
                          pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
@@ -922,6 +945,11 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   const int R = d->stride;
   if (d->tile < 0 || d->tile >= CG_NUM_TILES) return CG_EINVAL;
   const TileCfg tc = kTileCfgs[d->tile];
+  if (d->out_shifts &&
+      (d->out_f32 || d->rowsumsq || d->out_seg_size < 1 || !d->side ||
+       d->side_rows < 1 || d->epilogue == CG_EPI_LN_LRELU ||
+       d->epilogue == CG_EPI_SIGMOID || d->epilogue == CG_EPI_LRELU))
+    return CG_EINVAL;
   if (d->epilogue == CG_EPI_LN_LRELU &&
       (tc.wgn != 2 || d->N > 128 || d->out_f32 || d->rowsumsq || !d->ln_gamma ||
        !d->ln_beta || !d->ln_h || !d->ln_mean || !d->ln_rstd))
@@ -972,6 +1000,8 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta;
   a.ln_h = reinterpret_cast<uint16_t*>(d->ln_h);
   a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_eps = d->ln_eps;
+  a.out_shifts = d->out_shifts; a.out_seg = d->out_seg_size;
+  a.side = reinterpret_cast<uint16_t*>(d->side); a.side_rows = d->side_rows;
   a.w_phase_stride = d->w_phase_stride;
   a.off_phase_step = d->off_phase_step;
   a.yoff_phase_step = d->yoff_phase_step;

@@ -177,7 +177,7 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
                y_stride=1, y_off=0, bias=None, mask_src=None, shifts=None,
                seg_size=1, epilogue=_lib.EPI_NONE, out_f32=False, nphase=1,
                w_phase_stride=0, off_phase_step=0, yoff_phase_step=0,
-               rowsumsq=None, w_parity_major=False, ln=None):
+               rowsumsq=None, w_parity_major=False, ln=None, out_shifts=None):
   d = ConvDesc()
   d.w_parity_major = int(bool(w_parity_major) and stride == 2)
   d.split_parity = 0
@@ -203,6 +203,10 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
   if small == 0 and stride == 2 and CK <= 32 and Lu % 128 == 0:
     small = 2
   d.tile = small
+  if out_shifts is not None:
+    sh_t, d.out_seg_size, side_t, d.side_rows = out_shifts
+    d._keep = d._keep + (sh_t, side_t)
+    d.out_shifts, d.side = sh_t.data_ptr(), side_t.data_ptr()
   if ln is not None:
     # LayerNorm + LeakyReLU in the producing launch (gamma, beta, h, mean,
     # rstd): the row statistics need the whole row in one workgroup
@@ -216,6 +220,10 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
   return d
 
 
+# CALCIUMGAN_FUSE_UNSHUFFLE=0: cg_unshuffle_mask as its own pass after every
+# input-gradient launch of the critic
+_FUSE_UNSHUFFLE = __import__('os').environ.get('CALCIUMGAN_FUSE_UNSHUFFLE',
+                                                '1') != '0'
 # CALCIUMGAN_FUSE_LN=0 keeps LayerNorm a separate pass (A/B, debugging)
 _FUSE_LN = __import__('os').environ.get('CALCIUMGAN_FUSE_LN', '1') != '0'
 
@@ -545,18 +553,32 @@ class _DisPlan(object):
                       lay.cin, lay.cout, shifts=sh, seg_size=seg_size,
                       dbias=net.params.grad_views[2 * i + 1], slot=i))
     # input-gradient chain: layer i (1-based l = i+1) maps delta[l] -> e[l-1]
+    # PhaseShuffle adjoint + LeakyReLU' mask in the input-gradient launch's
+    # epilogue (rows stored at their source positions, masked there) when the
+    # reflected and the empty rows of a sample cannot coincide; the at most m
+    # reflected rows per sample go through `side` and cg_unshuffle_fixup
+    m = max(1, int(net.hp.m))
+    self.side = {}
     for i in range(len(net.layers) - 1, 0, -1):
       lay = net.layers[i]
       op = net.w_dgrad[i]
+      fused = _FUSE_UNSHUFFLE and 2 * m + 1 <= lay.lin
+      extra = {}
+      if fused:
+        self.side[i] = torch.zeros(nB, m, lay.cinp, dtype=BF16, device=dev)
+        extra = dict(mask_src=ws.act[i], epilogue=_lib.EPI_MASK,
+                     out_shifts=(self.shifts[i - 1], seg_size, self.side[i], m))
       self.dgrad.append((i,
-                         _conv_desc(ws.delta[i + 1], op.buf, ws.e[i], nB,
+                         _conv_desc(ws.delta[i + 1], op.buf,
+                                    ws.delta[i] if fused else ws.e[i], nB,
                                     lay.lout, lay.coutp, k // 2, 1,
                                     net.dgrad_offs[0], lay.lin // 2, lay.cin,
                                     lay.lin, lay.cinp, op.CK, y_stride=2,
                                     y_off=0, nphase=2,
                                     w_phase_stride=op.elems,
                                     off_phase_step=net.dgrad_offs[1] -
-                                    net.dgrad_offs[0], yoff_phase_step=1)))
+                                    net.dgrad_offs[0], yoff_phase_step=1,
+                                    **extra)))
     self.input_grad = None
     self.gin = None
     if input_grad_from is not None:
@@ -622,9 +644,15 @@ class _DisPlan(object):
     for i, d in self.dgrad:
       _run_conv(d, st)
       lay = net.layers[i - 1]
-      _lib.call('cg_unshuffle_mask', _p(ws.e[i]), _p(ws.act[i]),
-                _p(ws.delta[i]), _p(self.shifts[i - 1]), self.nB, lay.lout,
-                lay.coutp, self.seg_size, LEAKY_ALPHA, st)
+      if i in self.side:
+        side = self.side[i]
+        _lib.call('cg_unshuffle_fixup', _p(side), _p(ws.act[i]),
+                  _p(ws.delta[i]), _p(self.shifts[i - 1]), self.nB, lay.lout,
+                  lay.coutp, self.seg_size, side.shape[1], LEAKY_ALPHA, st)
+      else:
+        _lib.call('cg_unshuffle_mask', _p(ws.e[i]), _p(ws.act[i]),
+                  _p(ws.delta[i]), _p(self.shifts[i - 1]), self.nB, lay.lout,
+                  lay.coutp, self.seg_size, LEAKY_ALPHA, st)
     if self.input_grad is not None:
       if self.sumsq is not None:
         self.sumsq.zero_()

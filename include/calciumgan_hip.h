@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 5
+#define CG_ABI_VERSION 6
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -123,6 +123,18 @@ typedef struct cg_conv_desc {
   float* ln_mean;        /* f32 [nB*Ly] */
   float* ln_rstd;        /* f32 [nB*Ly] */
   float ln_eps;
+  /* Output-side PhaseShuffle adjoint (input gradient of a layer whose input
+   * was shuffled, calciumgan.py:117-138): output row t of sample b belongs to
+   * source row r = shuffle_src(t, out_shifts[b / out_seg_size], Ly).  Rows on
+   * the direct branch are stored at r (bias / mask epilogues read row r); rows
+   * on the reflected branch (at most |shift| per sample) go unmasked to
+   * side[b][j] and are folded in by cg_unshuffle_fixup, which also zeroes the
+   * |shift| rows nothing maps to.  NULL: rows are stored where they are
+   * computed.  bf16 output only. */
+  const int* out_shifts;
+  int out_seg_size;
+  void* side;           /* bf16 [nB][side_rows][Cy] */
+  int side_rows;        /* >= max |shift| */
 } cg_conv_desc;
 
 int cg_swconv(const cg_conv_desc* d, void* stream);
@@ -212,6 +224,14 @@ long long cg_wgrad_partials_elems(const cg_wgrad_desc* d);
  * the summation order differs); descriptors with `partials` are reduced by one
  * extra launch for all layers. */
 int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream);
+
+/* Second half of cg_conv_desc.out_shifts: per sample with shift s,
+ *   delta[b, r, :] = 0 for the |s| rows r no output row maps to, and
+ *   delta[b, r, :] += side[b, j, :] * (h[b, r, :] > 0 ? 1 : alpha) for the |s|
+ * reflected rows.  delta / h bf16 [nB][w][Cp], side bf16 [nB][side_rows][Cp]. */
+int cg_unshuffle_fixup(const void* side, const void* h, void* delta,
+                       const int* shifts, int nB, int w, int Cp, int seg_size,
+                       int side_rows, float alpha, void* stream);
 
 /* ---------------------------------------------------------------------------
  * LayerNormalization(axis=-1, eps) + LeakyReLU, one wavefront per row.

@@ -522,6 +522,68 @@ def test_layernorm_lrelu_fwd_bwd(rows, C):
                              rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('nB,L,Ci,Co,k,seg,m', [(6, 128, 102, 64, 24, 2, 10),
+                                                (5, 32, 64, 128, 24, 1, 3),
+                                                (4, 512, 32, 64, 8, 4, 2),
+                                                (3, 64, 16, 40, 24, 1, 0)])
+def test_dgrad_with_fused_unshuffle(nB, L, Ci, Co, k, seg, m):
+  """Input gradient of a strided conv whose input was phase-shuffled, with the
+  shuffle adjoint + LeakyReLU' mask in the launch's epilogue
+  (cg_conv_desc.out_shifts + cg_unshuffle_fixup) == the plain launch followed
+  by cg_unshuffle_mask: identical on every row that receives one contribution,
+  one bf16 rounding apart on the <= m rows per sample that receive two."""
+  rng = np.random.RandomState(41)
+  W = H.int_tensor(rng, (k, Ci, Co), -1, 1, 0.5)
+  dy = H.int_tensor(rng, (nB, L // 2, Co), -2, 2)
+  h = torch.tensor(rng.randn(nB, L, Ci).astype(np.float32))
+  nseg = (nB + seg - 1) // seg
+  shifts = rng.randint(-m, m + 1, size=nseg).astype(np.int32)
+  if m:
+    shifts[0], shifts[-1] = m, -m
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  pl = geo.same_padding_left(k, 2)
+  phases = nets._transpose_phases(k, pl)
+  offs = [o for _, o in phases]
+  ck = nets._ck_for(cop, 1, k // 2, L // 2)
+  op = H.pack(W.to(H.DEV), [(t0, -2, Ci * Co, 1, Co) for t0, _ in phases], Co,
+              Ci, cop, ck, k // 2)
+  dyd, hd = H.to_pitch(dy, cop), H.to_pitch(h, cip)
+  sh = torch.tensor(shifts, device=H.DEV)
+  common = dict(y_stride=2, y_off=0, nphase=2, w_phase_stride=op.elems,
+                off_phase_step=offs[1] - offs[0], yoff_phase_step=1)
+  z = lambda *s_: torch.zeros(*s_, dtype=BF16, device=H.DEV)
+  e, d0 = z(nB, L, cip), z(nB, L, cip)
+  da = H.conv_desc(dyd, op.buf, e, nB, L // 2, cop, k // 2, 1, offs[0], L // 2,
+                   Ci, L, cip, ck, **common)
+  H.run_conv(da)
+  _lib.call('cg_unshuffle_mask', H.p(e), H.p(hd), H.p(d0), H.p(sh), nB, L, cip,
+            seg, ALPHA, H.stream())
+  sr = max(1, m)
+  side = z(nB, sr, cip)
+  d1 = torch.full((nB, L, cip), 9.0, dtype=BF16, device=H.DEV)
+  db = H.conv_desc(dyd, op.buf, d1, nB, L // 2, cop, k // 2, 1, offs[0], L // 2,
+                   Ci, L, cip, ck, mask_src=hd, epilogue=_lib.EPI_MASK,
+                   out_shifts=(sh, seg, side, sr), **common)
+  H.run_conv(db)
+  _lib.call('cg_unshuffle_fixup', H.p(side), H.p(hd), H.p(d1), H.p(sh), nB, L,
+            cip, seg, sr, ALPHA, H.stream())
+  H.sync()
+  a, b = d0.float().cpu().numpy(), d1.float().cpu().numpy()
+  twice = np.zeros((nB, L), bool)  # rows with a direct and a reflected source
+  for i in range(nB):
+    s_ = int(shifts[i // seg])
+    if s_ > 0:
+      twice[i, L - 1 - s_:L - 1] = True
+    elif s_ < 0:
+      twice[i, 1:-s_ + 1] = True
+  np.testing.assert_array_equal(b[~twice], a[~twice])
+  # (the first contribution is rounded to bf16 on its own: half an ulp of it)
+  emax = float(e.float().abs().max())
+  np.testing.assert_allclose(b[twice], a[twice], rtol=2 ** -7,
+                             atol=2 ** -8 * emax)
+  assert float(np.abs(a).max()) > 0
+
+
 @pytest.mark.parametrize('w,m', [(16, 3), (64, 10), (8, 1)])
 def test_unshuffle_mask_is_adjoint_of_shuffle(w, m):
   rng = np.random.RandomState(11)
