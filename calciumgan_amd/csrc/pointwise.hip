@@ -595,13 +595,23 @@ __global__ __launch_bounds__(kThreads) void colsum_kernel(
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (rl < rlanes) {
     const long long r0 = (long long)blockIdx.x * rows_per_block;
-    for (int rr = rl; rr < rows_per_block; rr += rlanes) {
-      const long long row = r0 + rr;
-      if (row >= rows) break;
-      float v[8];
-      load8(x + row * Cp + grp * 8, v);
+    // four rows' loads in flight per thread before the first add
+    for (int rr = rl; rr < rows_per_block; rr += 4 * rlanes) {
+      uint4 raw[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      for (int k = 0; k < 4; ++k) {
+        const long long row = r0 + rr + k * rlanes;
+        raw[k] = (rr + k * rlanes < rows_per_block && row < rows)
+                     ? ldg16(x + row * Cp + grp * 8)
+                     : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v[8];
+        unpack8(raw[k], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) atomicAdd(&sacc[grp * 8 + e], acc[e]);

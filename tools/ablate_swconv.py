@@ -71,8 +71,27 @@ def direct_b(s):
   return s
 
 
+def stagger(n):
+  """Phase-shift the co-resident workgroups of the first dispatch round (their
+  epilogue store bursts / staging bursts then do not coincide)."""
+  def f(s):
+    return sub(
+        s, '  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n'
+        '  constexpr int WGM',
+        '  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];\n'
+        '  if (blockIdx.x < 768) {\n'
+        '    const int slot = (blockIdx.x >> 8) %% 3;\n'
+        '    for (int i = 0; i < slot * %d; ++i) __builtin_amdgcn_s_sleep(32);\n'
+        '  }\n'
+        '  constexpr int WGM' % n)
+  return f
+
+
 VARIANTS = {
     'base': lambda s: s,
+    'stag3': stagger(3),
+    'stag6': stagger(6),
+    'stag10': stagger(10),
     'directb': direct_b,
     'noepi': no_epilogue,
     'noa': no_a_staging,
@@ -98,7 +117,8 @@ def main():
     subprocess.check_call([
         '/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC',
         '-o', os.path.join(OUT, 'lib_%s.so' % name), obj,
-        os.path.join(SRC, 'wgrad.o'), os.path.join(SRC, 'pointwise.o')])
+        os.path.join(SRC, 'wgrad.o'), os.path.join(SRC, 'pointwise.o'),
+        os.path.join(SRC, 'dense_rows.o')])
     print('built', name)
 
 

@@ -2,6 +2,7 @@
 """Micro-benchmark of single cg_swconv / cg_wgrad launches (development tool).
 
   python tools/bench_conv.py conv  R taps nB Lx Cx N [CK] [small] [epi] [f32]
+                                   [ksteps] [rowsumsq]
   python tools/bench_conv.py wgrad R taps nB Lx Cx Cg [nsplit]
 Lx is the source length; outputs Lu = Lx/2 (R=2) or Lx (R=1, 2 phases when
 taps > 1)."""
@@ -42,6 +43,7 @@ def main():
     epi = a[8] if len(a) > 8 else 0
     f32 = a[9] if len(a) > 9 else 0
     ksteps = a[10] if len(a) > 10 else 0
+    ssq = torch.zeros(nB, device=dev) if len(a) > 11 and a[11] else None
     nphase = 2 if (R == 1 and taps > 1) else 1
     Lu = Lx // 2 if R == 2 else Lx
     Ly = Lu * (2 if nphase == 2 else 1)
@@ -61,7 +63,7 @@ def main():
                         y_stride=nphase, bias=bias, epilogue=epi,
                         mask_src=y if epi == 2 else None, out_f32=bool(f32),
                         nphase=nphase, w_phase_stride=op.elems,
-                        off_phase_step=1, yoff_phase_step=1)
+                        off_phase_step=1, yoff_phase_step=1, rowsumsq=ssq)
     if small >= 0:
       d.tile = small
     d.stage_ksteps = ksteps
