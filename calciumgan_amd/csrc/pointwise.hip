@@ -682,6 +682,65 @@ __global__ __launch_bounds__(kThreads) void signal_metrics_kernel(
   const long long wave_id = (long long)blockIdx.x * 4 + wave;
   const long long row0 = wave_id * (long long)rpw * rows_per_slot + slot;
   const float invC = 1.f / C;
+  if (C <= lpr * 8) {
+    // one 8-channel group per lane covers the row: two rows of both tensors
+    // are loaded before the first reduction and stay in registers for the
+    // second (variance) pass
+    const int c = sub * 8;
+    const int nv = C - c;
+    for (int it0 = 0; it0 < rows_per_slot; it0 += 2) {
+      float v[2][2][8];
+      bool rvk[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const long long row = row0 + (long long)(it0 + k) * rpw;
+        rvk[k] = it0 + k < rows_per_slot && row < rows;
+        if (rvk[k] && nv > 0) {
+          load8f(real + row * Cr + c, nv, Cr, v[k][0]);
+          load8f(fake + row * Cf + c, nv, Cf, v[k][1]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float st[2][4];
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          float mn = INFINITY, mx = -INFINITY, sum = 0.f;
+          float t[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const bool ok = rvk[k] && e < nv;
+            t[e] = ok ? v[k][which][e] * scale + smin : 0.f;
+            mn = ok ? fminf(mn, t[e]) : mn;
+            mx = ok ? fmaxf(mx, t[e]) : mx;
+            sum += t[e];
+          }
+          for (int o = lpr >> 1; o > 0; o >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, o, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+          }
+          const float mean = group_sum(sum, lpr) * invC;
+          float s2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = t[e] - mean;
+            s2 += (rvk[k] && e < nv) ? d * d : 0.f;
+          }
+          st[which][0] = mn;
+          st[which][1] = mx;
+          st[which][2] = mean;
+          st[which][3] = sqrtf(group_sum(s2, lpr) * invC);
+        }
+        if (rvk[k] && sub == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float d = st[0][q] - st[1][q];
+            acc[q] += d * d;
+          }
+        }
+      }
+    }
+  } else
   for (int it = 0; it < rows_per_slot; ++it) {
     const long long row = row0 + (long long)it * rpw;
     const bool rv = row < rows;
@@ -981,7 +1040,11 @@ extern "C" int cg_signal_metrics(const float* real, const float* fake,
   int lpr = 1, l2 = 0;
   while (lpr * 8 < C && lpr < 64) { lpr <<= 1; ++l2; }
   const int rpw = 64 / lpr;
-  const int rows_per_slot = 4;
+  // every block ends with 4 atomics on the same 4 addresses, which serialise:
+  // ~1024 blocks on the large inputs
+  int rows_per_slot = 4;
+  while (rows_per_slot < 64 && rows / ((long long)4 * rpw * rows_per_slot) > 1024)
+    rows_per_slot *= 2;
   hipLaunchKernelGGL(signal_metrics_kernel,
                      dim3(grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31)),
                      dim3(kThreads), 0, S_(stream), real, fake, out, rows, C,

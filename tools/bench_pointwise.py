@@ -68,6 +68,20 @@ def main():
     nbytes = nB * w * C * 6
     print('unshuffle nB %d w %4d C %3d: %6.1f us  %.2f TB/s' % (
         nB, w, C, t * 1e6, nbytes / t / 1e12))
+  # generator-step signal metrics and the output Dense bias gradient
+  rows, C, Cp = B * 2048, 102, 128
+  real = torch.rand(rows, C, device=dev)
+  fake = torch.rand(rows, Cp, device=dev)
+  out = torch.zeros(4, device=dev)
+  t = timeit(lambda: _lib.call('cg_signal_metrics', P(real), P(fake), P(out), rows,
+                               C, C, Cp, 0.0, 1.0, st))
+  print('signal_metrics rows %d: %6.1f us  %.2f TB/s' % (
+      rows, t * 1e6, rows * (C + Cp) * 4 / t / 1e12))
+  dz = torch.randn(rows, Cp, device=dev).to(BF16)
+  cs = torch.zeros(C, device=dev)
+  t = timeit(lambda: _lib.call('cg_colsum', P(dz), P(cs), rows, C, Cp, st))
+  print('colsum rows %d: %6.1f us  %.2f TB/s' % (rows, t * 1e6,
+                                                 rows * Cp * 2 / t / 1e12))
 
 
 if __name__ == '__main__':
