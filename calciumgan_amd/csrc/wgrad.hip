@@ -631,8 +631,9 @@ int launch_reduce(const ReduceArgs& ra, hipStream_t s) {
   }
   long long bx = (most + 255) / 256;
   if (bx > 2048) bx = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)bx, ra.n), dim3(256), 0, s,
-                     ra);
+  // (timed with the wgrad family: it is the second half of those launches)
+  CG_LAUNCH_PROF(CG_FAMILY_WGRAD, wgrad_reduce_kernel, dim3((unsigned)bx, ra.n),
+                 dim3(256), 0, s, ra);
   CG_LAUNCH_CHECK();
 }
 
