@@ -82,12 +82,19 @@ def algorithmic_bytes_swconv(hp, B):
     return nb * (lay.lin * lay.cinp * 2 + lay.lout * lay.coutp * out_bytes) + \
         k * lay.cinp * lay.cout * 2
 
-  def dgrad(nb, lay, out_bytes=2):  # D input gradient (two phases)
-    return nb * (lay.lout * lay.coutp * 2 + lay.lin * lay.cinp * out_bytes) + \
+  def dgrad(nb, lay, out_bytes=2, masked=False):  # D input gradient (2 phases)
+    # masked: the phase-unshuffle + LeakyReLU' mask fused into the epilogue
+    # reads the activation it masks with
+    return nb * (lay.lout * lay.coutp * 2 + lay.lin * lay.cinp * out_bytes +
+                 (lay.lin * lay.cinp * 2 if masked else 0)) + \
         k * lay.coutp * lay.cin * 2
 
   def convT(nb, lay):  # G conv-transpose fwd (two phases)
-    return nb * (lay.lin * lay.cinp * 2 + lay.lout * lay.coutp * 2) + \
+    # rows of <= 128 channels: LayerNorm + LeakyReLU fused -- the launch also
+    # writes the activation and the row statistics
+    ln = lay.lout * (lay.coutp * 2 + 8) if (hp.layer_norm and
+                                            lay.cout <= 128) else 0
+    return nb * (lay.lin * lay.cinp * 2 + lay.lout * lay.coutp * 2 + ln) + \
         k * lay.cinp * lay.cout * 2
 
   def convT_dgrad(nb, lay):
@@ -102,9 +109,12 @@ def algorithmic_bytes_swconv(hp, B):
   g_bwd = B * L * (cp * 2 + cp * 2) + cp * C * 2
   g_bwd += sum(convT_dgrad(B, l) for l in g_l)
   d_fwd = lambda nb: sum(conv(nb, l) for l in d_l)
-  critic = g_fwd + d_fwd(3 * B) + sum(dgrad(3 * B, l) for l in d_l[1:])
+  fusable = lambda l: 2 * max(1, hp.m) + 1 <= l.lin
+  critic = g_fwd + d_fwd(3 * B) + sum(dgrad(3 * B, l, masked=fusable(l))
+                                      for l in d_l[1:])
   critic += dgrad(B, d_l[0]) + d_fwd(B)  # x^ input gradient + tangent chain
-  gen = g_fwd + d_fwd(B) + sum(dgrad(B, l) for l in d_l[1:]) + \
+  gen = g_fwd + d_fwd(B) + sum(dgrad(B, l, masked=fusable(l))
+                               for l in d_l[1:]) + \
       dgrad(B, d_l[0]) + g_bwd
   g_launches = 6 if streaming else 7
   launches = n * (g_launches + 5 + 4 + 1 + 5) + (g_launches + 5 + 4 + 1 + 6)

@@ -16,7 +16,9 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     for f in glob.glob('gpurun_out/traffic_%s/*/*counter_collection.csv' % c):
         for r in csv.DictReader(open(f)):
             n = r['Kernel_Name']
-            fam = 'swconv' if 'swconv_kernel' in n else ('wgrad' if 'wgrad_' in n else None)
+            fam = ('swconv' if 'swconv_kernel' in n else
+                   'wgrad_reduce' if 'wgrad_reduce' in n else
+                   'wgrad' if 'wgrad_' in n else None)
             if fam is None or r['Counter_Name'] != c:
                 continue
             a = res[fam][c]
