@@ -214,7 +214,9 @@ swconv_kernel(ConvArgs a) {
       boff[ks][kh] =
           (wn * 64 + rM) * kRowB + (((4 * ks + 2 * kh + g) ^ swz) * 8);
   issue_dma(0);
-  if (total_stages > 1) issue_dma(1);
+#pragma unroll
+  for (int i = 1; i < kNBufB - 1; ++i)
+    if (i < total_stages) issue_dma(i);
 
   const int nst_part = nstages / NPART;  // weight stages per staged part
   const int half_taps = a.taps >> 1;
@@ -351,17 +353,21 @@ swconv_kernel(ConvArgs a) {
       const int goff = UNI ? g * 8 : 0;
       for (int s = part * nst_part; s < (part + 1) * nst_part; ++s) {
         const int gs = cc * nstages + s;
-        // stage gs has landed once all but this wave's newest NDMA DMAs are
-        // done (only DMA(gs+1) may stay in flight); the barrier then (a) makes
-        // every wave's part of stage gs visible and (b) guarantees slot
-        // (gs+2) % 3 == (gs-1) % 3 is no longer being read before it is refilled
-        if (gs + 1 < total_stages)
+        // stage gs has landed once all but this wave's newest (ring depth - 2)
+        // stages of DMAs are done (only DMA(gs+1 ..) may stay in flight); the
+        // barrier then (a) makes every wave's part of stage gs visible and (b)
+        // guarantees the slot of stage gs-1 is no longer being read before it
+        // is refilled with stage gs + depth - 1
+        const int ahead = total_stages - 1 - gs;  // later stages, issued or not
+        if (ahead >= kNBufB - 2)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kNBufB - 2) * NDMA) : "memory");
+        else if (kNBufB > 3 && ahead == 1)
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         else
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // window stores
         __builtin_amdgcn_s_barrier();
-        if (gs + 2 < total_stages) issue_dma(gs + 2);
+        if (gs + kNBufB - 1 < total_stages) issue_dma(gs + kNBufB - 1);
         const uint16_t* curB = ldsB + (gs % kNBufB) * kBufB;
         // PIPE instantiations: the fragments of K-step ks+1 are read into a
         // second register set before the MFMAs of K-step ks issue, and a

@@ -89,6 +89,7 @@ def stagger(n):
 
 VARIANTS = {
     'base': lambda s: s,
+    'ring4': lambda s: sub(s, 'constexpr int kNBufB = 3;', 'constexpr int kNBufB = 4;'),
     'stag3': stagger(3),
     'stag6': stagger(6),
     'stag10': stagger(10),
