@@ -45,6 +45,7 @@ class ConvDesc(C.Structure):
       ('split_parity', c_i),
       ('ln_gamma', c_vp), ('ln_beta', c_vp), ('ln_h', c_vp),
       ('ln_mean', c_vp), ('ln_rstd', c_vp), ('ln_eps', c_f),
+      ('w_narrow_last', c_i),
       ('out_shifts', c_vp), ('out_seg_size', c_i), ('side', c_vp),
       ('side_rows', c_i),
   ]
@@ -58,6 +59,7 @@ class PackDesc(C.Structure):
       ('s_tap', c_ll), ('s_c', c_ll), ('s_n', c_ll),
       ('C_real', c_i), ('N_real', c_i), ('Cx', c_i), ('CK', c_i),
       ('parity_major', c_i),
+      ('narrow_last', c_i),
   ]
 
 

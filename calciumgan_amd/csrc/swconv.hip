@@ -60,6 +60,7 @@ struct ConvArgs {
   float* ln_mean;
   float* ln_rstd;
   float ln_eps;
+  int narrow;      // last channel chunk packed narrow (cg_pack_desc.narrow_last)
   // output-side phase-shuffle adjoint (see cg_conv_desc.out_shifts)
   const int* out_shifts;
   int out_seg;
@@ -190,7 +191,9 @@ swconv_kernel(ConvArgs a) {
     dsrc[i] = wp + (long long)(n0 + row) * a.Kpack + c * 8;
   }
   const int nstages = a.Fp / FS;
-  const int total_stages = a.nchunks * nstages;
+  // narrow last chunk: 32 K groups (16 per tap parity) instead of taps * 4
+  const int total_stages =
+      a.narrow ? (a.nchunks - 1) * nstages + 32 / FS : a.nchunks * nstages;
   auto issue_dma = [&](int gs) {
     // packed weights are contiguous over (chunk, stage): offset gs * FS * 8
     uint16_t* slot = ldsB + (gs % kNBufB) * kBufB;
@@ -350,8 +353,11 @@ swconv_kernel(ConvArgs a) {
     // wave-uniform (scalar registers, lane part g*8 folded into the row base);
     // otherwise (e.g. c8 = 13) every lane tracks its own (tap, group).
     {
-      const int goff = UNI ? g * 8 : 0;
-      for (int s = part * nst_part; s < (part + 1) * nst_part; ++s) {
+      const bool narrow_now = R == 2 && UNI && a.narrow && cc == a.nchunks - 1;
+      const int goff = (UNI && !narrow_now) ? g * 8 : 0;
+      const int nsp = narrow_now ? (32 / FS) / NPART : nst_part;
+      int npos = part * 4;  // narrow walk: K-step counter (4 per tap parity)
+      for (int s = part * nsp; s < (part + 1) * nsp; ++s) {
         const int gs = cc * nstages + s;
         // stage gs has landed once all but this wave's newest (ring depth - 2)
         // stages of DMAs are done (only DMA(gs+1 ..) may stay in flight); the
@@ -389,6 +395,32 @@ swconv_kernel(ConvArgs a) {
                    q8l * 8;
           } else {
             aoff = ti * a.pitchA + q8l * 8;
+          }
+          if constexpr (R == 2 && UNI) {
+            if (narrow_now) {
+              // the four k-groups of a K-step are four consecutive taps of one
+              // parity (same 8 channels): k-group p of K-step npos reads window
+              // row (4 * (npos & 3) + p) of parity region npos >> 2; slots past
+              // taps/2 carry zero weights (row clamped: LDS may hold anything)
+              const int kq = 4 * (npos & 3);
+              const int reg = SP ? 0 : (npos >> 2) * regionRows;
+              ++npos;
+#pragma unroll
+              for (int kh = 0; kh < KH; ++kh) {
+                int idx = kq + (MF == 32 ? 2 * kh : 0) + g;
+                idx = idx < half_taps ? idx : half_taps - 1;
+                aoff = (reg + idx) * a.pitchA;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                  bfrag[buf][kh][nt] = *reinterpret_cast<const bf16x8*>(
+                      curB + nt * MF * kRowB + boff[ks][kh]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                  afrag[buf][kh][mt] = *reinterpret_cast<const bf16x8*>(
+                      ldsA + rowbase[mt] + aoff);
+              }
+              return;
+            }
           }
 #pragma unroll
           for (int kh = 0; kh < KH; ++kh) {
@@ -667,6 +699,7 @@ struct PackArgs {
   int C_real, N_real, CK, c8, nchunks, Fp;
   long long Kpack, total;
   int parity_major;  // packed tap i holds tap 2i (i < taps/2) else 2(i-taps/2)+1
+  int narrow_last;   // last chunk: 8 channels per tap, 16 slots per tap parity
 };
 
 // One thread packs one 16-byte group: 8 consecutive channels of one
@@ -692,14 +725,22 @@ __device__ __forceinline__ void pack_group(const PackArgs& a, long long r) {
     cc = (int)(q % a.nchunks);
     n = (int)(q / a.nchunks);
   }
-  const int tap = f / a.c8;
-  const int q8 = f - tap * a.c8;
+  int tap = f / a.c8;
+  int q8 = f - tap * a.c8;
+  const int half = a.taps >> 1;
+  if (a.narrow_last && cc == a.nchunks - 1) {
+    // narrow last chunk (<= 8 real channels): position f < 32 is the first
+    // 8-channel group of tap parity f >> 4, index f & 15 (slots past taps/2
+    // and positions >= 32 stay zero; the kernel stops after position 31)
+    const int idx = f & 15;
+    tap = (f < 32 && idx < half) ? (f >> 4) * half + idx : a.taps;
+    q8 = 0;
+  }
   const int c = cc * a.CK + q8 * 8;
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = 0.f;
   if (tap < a.taps && n < a.N_real) {
-    const int half = a.taps >> 1;
     const int tsrc = !a.parity_major ? tap
                      : tap < half   ? 2 * tap
                                     : 2 * (tap - half) + 1;
@@ -804,13 +845,20 @@ extern "C" long long cg_packed_elems(int N, int taps, int Cx, int CK) {
   return Npad * (long long)(Cx / CK) * Fp * 8;
 }
 
+static bool narrow_ok(const cg_pack_desc* d) {
+  return !d->narrow_last ||
+         (d->parity_major && d->CK == 32 && d->taps <= 32 && !(d->taps & 1) &&
+          d->Cx >= 64 && d->C_real > d->Cx - 32 && d->C_real <= d->Cx - 24);
+}
+
 static int fill_pack_args(const cg_pack_desc* d, PackArgs& a) {
   const long long total = cg_packed_elems(d->N_real, d->taps, d->Cx, d->CK);
-  if (total < 0 || d->C_real > d->Cx) return CG_EINVAL;
+  if (total < 0 || d->C_real > d->Cx || !narrow_ok(d)) return CG_EINVAL;
   a.src = d->src;
   a.dst = reinterpret_cast<uint16_t*>(d->dst);
   a.taps = d->taps; a.tap0 = d->tap0; a.tap_step = d->tap_step;
   a.parity_major = d->parity_major;
+  a.narrow_last = d->narrow_last;
   a.s_tap = d->s_tap; a.s_c = d->s_c; a.s_n = d->s_n;
   a.C_real = d->C_real; a.N_real = d->N_real; a.CK = d->CK;
   a.c8 = d->CK / 8; a.nchunks = d->Cx / d->CK;
@@ -862,12 +910,13 @@ extern "C" int cg_pack_batched(const void* dev_plan, int n, long long blocks,
 
 extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {
   const long long total = cg_packed_elems(d->N_real, d->taps, d->Cx, d->CK);
-  if (total < 0 || d->C_real > d->Cx) return CG_EINVAL;
+  if (total < 0 || d->C_real > d->Cx || !narrow_ok(d)) return CG_EINVAL;
   PackArgs a;
   a.src = d->src;
   a.dst = reinterpret_cast<uint16_t*>(d->dst);
   a.taps = d->taps; a.tap0 = d->tap0; a.tap_step = d->tap_step;
   a.parity_major = d->parity_major;
+  a.narrow_last = d->narrow_last;
   a.s_tap = d->s_tap; a.s_c = d->s_c; a.s_n = d->s_n;
   a.C_real = d->C_real; a.N_real = d->N_real; a.CK = d->CK;
   a.c8 = d->CK / 8; a.nchunks = d->Cx / d->CK;
@@ -1012,6 +1061,12 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta;
   a.ln_h = reinterpret_cast<uint16_t*>(d->ln_h);
   a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_eps = d->ln_eps;
+  a.narrow = 0;
+  if (d->w_narrow_last) {
+    if (R != 2 || !a.pmajor || d->CK != 32 || a.nchunks < 2 || d->taps > 32)
+      return CG_EINVAL;
+    a.narrow = 1;
+  }
   a.out_shifts = d->out_shifts; a.out_seg = d->out_seg_size;
   a.side = reinterpret_cast<uint16_t*>(d->side); a.side_rows = d->side_rows;
   a.w_phase_stride = d->w_phase_stride;

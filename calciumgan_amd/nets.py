@@ -79,6 +79,10 @@ class FlatParams(object):
       v.copy_(torch.from_numpy(w))
 
 
+# CALCIUMGAN_NARROW_LAST=0: padded channel chunks are walked in full
+_NARROW_LAST = __import__('os').environ.get('CALCIUMGAN_NARROW_LAST', '1') != '0'
+
+
 class PackedOperand(object):
   """bf16 MFMA operand of one (layer, direction), produced from the f32 master
   tensor by cg_pack_weights in the K order cg_swconv walks."""
@@ -89,6 +93,12 @@ class PackedOperand(object):
     launch walks them with w_parity_major (needed for split-parity staging)."""
     lib = _lib.load()
     self.parity_major = bool(parity_major)
+    # channel padding of the last 32-channel chunk (102 -> 128: 6 real
+    # channels of 32): packed as ONE 8-channel group per tap, so a launch
+    # walks 32 K groups of that chunk instead of taps * 4
+    self.narrow_last = bool(_NARROW_LAST and self.parity_major and CK == 32 and
+                            Cx >= 64 and taps <= 32 and
+                            Cx - 32 < C_real <= Cx - 24)
     self.elems = lib.cg_packed_elems(N_real, taps, Cx, CK)
     if self.elems < 0:
       raise ValueError('bad packing geometry')
@@ -106,6 +116,7 @@ class PackedOperand(object):
       d.s_tap, d.s_c, d.s_n = s_tap, s_c, s_n
       d.C_real, d.N_real, d.Cx, d.CK = C_real, N_real, Cx, CK
       d.parity_major = int(self.parity_major)
+      d.narrow_last = int(self.narrow_last)
       self.descs.append(d)
 
   def repack(self):
@@ -177,9 +188,11 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
                y_stride=1, y_off=0, bias=None, mask_src=None, shifts=None,
                seg_size=1, epilogue=_lib.EPI_NONE, out_f32=False, nphase=1,
                w_phase_stride=0, off_phase_step=0, yoff_phase_step=0,
-               rowsumsq=None, w_parity_major=False, ln=None, out_shifts=None):
+               rowsumsq=None, w_parity_major=False, ln=None, out_shifts=None,
+               w_narrow_last=False):
   d = ConvDesc()
   d.w_parity_major = int(bool(w_parity_major) and stride == 2)
+  d.w_narrow_last = int(bool(w_narrow_last) and d.w_parity_major)
   d.split_parity = 0
   d._keep = (x, w, y, bias, mask_src, shifts, rowsumsq)  # borrowed pointers
   d.rowsumsq = rowsumsq.data_ptr() if rowsumsq is not None else None
@@ -276,7 +289,7 @@ def _autotune_tile(d):
   if not torch.cuda.is_available():
     return
   key = (d.stride, d.taps, d.nB, d.Lx, d.Cx, d.Lu, d.N, d.CK, d.nphase,
-         d.epilogue, d.out_f32)
+         d.epilogue, d.out_f32, d.w_narrow_last)
   best = _TILE_CACHE.get(key)
   if best is None and not _AUTOTUNE:
     return
@@ -546,7 +559,8 @@ class _DisPlan(object):
           _conv_desc(ws.act[i], op.buf, ws.act[i + 1], nB, lay.lin, lay.cinp, k,
                      2, -pl, lay.lout, lay.cout, lay.lout, lay.coutp, op.CK,
                      bias=bias, shifts=sh, seg_size=seg_size,
-                     epilogue=_lib.EPI_LRELU, w_parity_major=op.parity_major))
+                     epilogue=_lib.EPI_LRELU, w_parity_major=op.parity_major,
+                     w_narrow_last=op.narrow_last))
       self.wgrad.append(
           _wgrad_desc(ws.act[i], ws.delta[i + 1], net.params.grad_views[2 * i],
                       nB, lay.lin, lay.cinp, lay.lout, lay.coutp, k, 2, -pl,
@@ -619,7 +633,8 @@ class _DisPlan(object):
                      lay.cinp, k, 2, -pl, lay.lout, lay.cout, lay.lout,
                      lay.coutp, op.CK, mask_src=seg_act, shifts=sh,
                      seg_size=n, epilogue=_lib.EPI_MASK,
-                     w_parity_major=op.parity_major))
+                     w_parity_major=op.parity_major,
+                     w_narrow_last=op.narrow_last))
 
   # -- schedules ------------------------------------------------------------
   def forward(self):
@@ -827,7 +842,8 @@ class _GenWorkspace(object):
       self.b_dgrad.append(
           _conv_desc(self.dy[i + 1], op.buf, self.dh[i], B, lay.lout, lay.coutp,
                      k, 2, -net.pl, lay.lin, lay.cin, lay.lin, lay.cinp, op.CK,
-                     w_parity_major=op.parity_major))
+                     w_parity_major=op.parity_major,
+                     w_narrow_last=op.narrow_last))
       self.b_wgrad.append(
           _wgrad_desc(self.dy[i + 1], self.h[i], G[ic], B, lay.lout, lay.coutp,
                       lay.lin, lay.cinp, k, 2, -net.pl, lay.cout, lay.cin,

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 6
+#define CG_ABI_VERSION 7
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -131,6 +131,8 @@ typedef struct cg_conv_desc {
    * side[b][j] and are folded in by cg_unshuffle_fixup, which also zeroes the
    * |shift| rows nothing maps to.  NULL: rows are stored where they are
    * computed.  bf16 output only. */
+  int w_narrow_last;    /* `w` was packed with narrow_last = 1 (stride 2,
+                           w_parity_major, CK == 32) */
   const int* out_shifts;
   int out_seg_size;
   void* side;           /* bf16 [nB][side_rows][Cy] */
@@ -169,6 +171,13 @@ typedef struct cg_pack_desc {
                        then the odd ones -- the order in which a stride-2 launch
                        with w_parity_major walks them (one source-row parity
                        at a time) */
+  int narrow_last;  /* 1 (needs parity_major, CK == 32, taps <= 32, and
+                       Cx - 32 < C_real <= Cx - 24: the last channel chunk
+                       holds at most 8 real channels): that chunk is packed as
+                       one 8-channel group per tap -- 16 slots per tap parity,
+                       K = 32 groups instead of taps*4 -- for launches with
+                       cg_conv_desc.w_narrow_last, which then skip the chunk's
+                       all-zero channel groups */
 } cg_pack_desc;
 int cg_pack_weights(const cg_pack_desc* d, void* stream);
 /* Batched form (one launch for all operands of a model).  Host side:

@@ -103,7 +103,9 @@ def _force_tile(d, tile, ks, sp=0):
 @pytest.mark.parametrize('tile,ks', ALL_TILES)
 @pytest.mark.parametrize('nB,L,Ci,Co,k,seg', [(2, 1024, 64, 192, 24, 1),
                                               (6, 128, 96, 102, 24, 2),
-                                              (3, 512, 32, 64, 8, 3)])
+                                              (3, 512, 32, 64, 8, 3),
+                                              (3, 1024, 102, 64, 24, 2),
+                                              (4, 64, 70, 40, 8, 4)])
 def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp):
   """Stride-2 forward with phase shuffle + bias + LeakyReLU on every workgroup
   tile (both MFMA shapes, 4x1 and 2x2 waves) and both weight-stage depths,
@@ -127,15 +129,25 @@ def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp):
   y = torch.full((nB, Lo, cop), 7.0, dtype=BF16, device=H.DEV)
   sh = torch.tensor(shifts, device=H.DEV)
   bd = b.to(H.DEV)
+  # Ci = 102 / 70 with parity-major weights: the last 32-channel chunk holds
+  # 6 real channels and is packed / walked narrow (cg_pack_desc.narrow_last)
+  assert op.narrow_last == (bool(sp) and Ci in (102, 70))
   d = H.conv_desc(xd, op.buf, y, nB, L, cip, k, 2, -pl, Lo, Co, Lo, cop, ck,
                   bias=bd, shifts=sh, seg_size=seg, epilogue=_lib.EPI_LRELU,
-                  w_parity_major=bool(sp))
+                  w_parity_major=bool(sp), w_narrow_last=op.narrow_last)
   _force_tile(d, tile, ks, sp)
   H.sync()
   got = y.float().cpu()
   np.testing.assert_array_equal(got[:, :, :Co].numpy(), ref.numpy())
   if cop > Co:
     assert float(got[:, :, Co:].abs().max()) == 0.0
+  if sp:
+    # the same parity-major (and narrow) operand with both parities resident
+    y.fill_(7.0)
+    _force_tile(d, tile, ks, 0)
+    H.sync()
+    np.testing.assert_array_equal(y.float().cpu()[:, :, :Co].numpy(),
+                                  ref.numpy())
 
 
 @pytest.mark.parametrize('tile,ks', ALL_TILES)
