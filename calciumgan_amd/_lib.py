@@ -16,7 +16,8 @@ EPI_NONE, EPI_LRELU, EPI_MASK, EPI_SIGMOID, EPI_LN_LRELU = 0, 1, 2, 3, 4
 # CG_TILE_*: value -> (rows, cols, mfma rows)
 TILES = {0: (256, 64, 16), 1: (64, 64, 16), 2: (128, 64, 16),
          3: (256, 64, 32), 4: (128, 64, 32), 5: (256, 128, 32),
-         6: (128, 128, 32), 7: (256, 128, 16)}
+         6: (128, 128, 32), 7: (256, 128, 16),
+         8: (128, 128, 16)}
 
 c_vp = C.c_void_p
 c_i = C.c_int

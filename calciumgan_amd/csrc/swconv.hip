@@ -106,7 +106,7 @@ constexpr int kScratchBytes = 4 * 16 * kScrPitch * 4;
 template <int R, int MF, int WGN, int MT, int KS, bool UNI, bool SP = false,
           bool LN = false>
 __global__ __launch_bounds__(256, ((MF == 32 && MT == 4) || MT == 8)    ? 2
-                                  : (MF == 16 && MT == 4 && KS == 2 && UNI) ? 3
+                                  : (MF == 16 && MT == 4 && KS == 2 && UNI && WGN == 1) ? 3
                                                                      : 1) void
 swconv_kernel(ConvArgs a) {
   static_assert(!SP || (R == 2 && UNI), "split-parity staging is a stride-2 mode");
@@ -983,6 +983,7 @@ static const TileCfg kTileCfgs[CG_NUM_TILES] = {
     {32, 2, 4},  // CG_TILE_256x128_M32
     {32, 2, 2},  // CG_TILE_128x128_M32
     {16, 2, 8},  // CG_TILE_256x128
+    {16, 2, 4},  // CG_TILE_128x128
 };
 
 extern "C" int cg_tile_shape(int tile, int* rows, int* cols) {
@@ -1104,6 +1105,7 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   CG_DISPATCH_RK(16, 1, 4) CG_DISPATCH_RK(16, 1, 1) CG_DISPATCH_RK(16, 1, 2)
   CG_DISPATCH_RK(32, 1, 2) CG_DISPATCH_RK(32, 1, 1)
   CG_DISPATCH_RK(32, 2, 4) CG_DISPATCH_RK(32, 2, 2) CG_DISPATCH_RK(16, 2, 8)
+  CG_DISPATCH_RK(16, 2, 4)
 #undef CG_DISPATCH_RK
 #undef CG_DISPATCH
   return CG_EINVAL;

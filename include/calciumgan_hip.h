@@ -48,7 +48,8 @@ extern "C" {
 #define CG_TILE_256x128_M32 5
 #define CG_TILE_128x128_M32 6
 #define CG_TILE_256x128 7
-#define CG_NUM_TILES 8
+#define CG_TILE_128x128 8
+#define CG_NUM_TILES 9
 
 int cg_abi_version(void);
 /* rows / columns of a CG_TILE_* value (host helper; CG_EINVAL if unknown) */

@@ -257,7 +257,7 @@ def test_conv_transpose_fwd_bitexact(B, L, Ci, Co, k):
 
 
 @pytest.mark.parametrize('tile,ks', [(5, 2), (5, 4), (6, 2), (6, 4), (7, 2),
-                                     (7, 4)])
+                                     (7, 4), (8, 2), (8, 4)])
 @pytest.mark.parametrize('B,L,Ci,Co,k', [(3, 256, 128, 102, 24),
                                           (2, 512, 192, 128, 24),
                                           (5, 16, 64, 40, 24),
