@@ -29,6 +29,8 @@ CONFIGS = {
     'm0_k8': (128, 6, 8, 8, 0, 3, True),       # no phase shuffle, 8-tap kernels
     'long': (2048, 6, 8, 24, 10, 2, True),     # cfg2 length / shifts: 256-row
                                                # tiles, fused penalty norm
+    'c40': (128, 40, 16, 24, 3, 2, True),      # 40 channels in a 64 pitch: the
+                                               # last chunk holds exactly 8
 }
 
 
