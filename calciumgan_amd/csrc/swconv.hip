@@ -585,14 +585,17 @@ swconv_kernel(ConvArgs a) {
                               (e < 4 ? b0[e] : b1[e - 4]);
               hv[e] = fmaxf(t, a.alpha * t);
             }
-            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.y) + rowoff +
-                                      nA) =
-                make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
-                           pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            // (forward-only callers -- G(z) of a critic update -- pass no
+            // statistics buffers: the pre-activation is then not stored either)
+            if (a.ln_mean)
+              *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.y) + rowoff +
+                                        nA) =
+                  make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
+                             pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
             *reinterpret_cast<uint4*>(a.ln_h + rowoff + nA) =
                 make_uint4(pack2bf(hv[0], hv[1]), pack2bf(hv[2], hv[3]),
                            pack2bf(hv[4], hv[5]), pack2bf(hv[6], hv[7]));
-            if (wn == 0 && cg8 == 0) {
+            if (a.ln_mean && wn == 0 && cg8 == 0) {
               a.ln_mean[ridx] = mean;
               a.ln_rstd[ridx] = rstd;
             }
@@ -1014,7 +1017,7 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
     return CG_EINVAL;
   if (d->epilogue == CG_EPI_LN_LRELU &&
       (tc.wgn != 2 || d->N > 128 || d->out_f32 || d->rowsumsq || !d->ln_gamma ||
-       !d->ln_beta || !d->ln_h || !d->ln_mean || !d->ln_rstd))
+       !d->ln_beta || !d->ln_h || (!d->ln_mean != !d->ln_rstd)))
     return CG_EINVAL;
   const int TM = (4 / tc.wgn) * tc.mt * tc.mf;
   const int TN = 64 * tc.wgn;

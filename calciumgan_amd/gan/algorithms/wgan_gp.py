@@ -93,7 +93,7 @@ class WGAN_GP(GAN):
     s = nets._stream()
     plan.shifts.copy_(shifts, non_blocking=True)
     if fake is None:
-      fake = st['gws'].forward(z)
+      fake = st['gws'].forward(z, keep=False)
     _lib.call('cg_interp_pack', nets._p(real), nets._p(fake), nets._p(alpha),
               nets._p(st['dws'].act[0]), B, lay.lin, lay.cin, lay.cin, lay.cinp,
               lay.cinp, 0 if real_cached else 1, s)
@@ -116,17 +116,18 @@ class WGAN_GP(GAN):
     return fake
 
   # -- the step, cut at the all-reduce points ---------------------------------
-  def _critic_generate(self, real, r=None):
+  def _critic_generate(self, real, r=None, keep=False):
     """fake = G(z) of one critic update (wgan_gp.py:65-67).  It reads no
     discriminator state, so train() runs it while the previous update's
-    gradient all-reduce is still in flight."""
+    gradient all-reduce is still in flight.  keep=True (the generator update's
+    own forward): activations stay for GeneratorNet's backward."""
     B = real.shape[0]
     st = self._get_state(B)
     if r is None or 'shifts_dev' in r:
       z = self.get_noise(B)
     else:
       z = self._to_device(r['z'])
-    return st['gws'].forward(z)
+    return st['gws'].forward(z, keep=keep)
 
   def _critic_compute(self, real, r=None, slot=0, real_cached=False,
                       fake=None):
@@ -186,7 +187,7 @@ class WGAN_GP(GAN):
     lay = net_d.layers[0]
     plan = st['gen']
     if fake is None:
-      fake = self._critic_generate(real, r)  # same op: fake = G(z)
+      fake = self._critic_generate(real, r, keep=True)  # same op: fake = G(z)
     if r is None:
       shifts = self._streams.shifts(1)
     elif 'shifts_dev' in r:
@@ -247,7 +248,9 @@ class WGAN_GP(GAN):
 
     def generate(key, r):
       def run():
-        box[key] = self._critic_generate(real, r)
+        # only the generator update's own forward ('g') is followed by a
+        # backward through G
+        box[key] = self._critic_generate(real, r, keep=key == 'g')
       return run
 
     def critic_seg(i, own_g):

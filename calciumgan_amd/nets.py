@@ -226,7 +226,7 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
     d._keep = d._keep + tuple(ln)
     d.epilogue = _lib.EPI_LN_LRELU
     d.ln_gamma, d.ln_beta, d.ln_h, d.ln_mean, d.ln_rstd = (
-        t.data_ptr() for t in ln)
+        None if t is None else t.data_ptr() for t in ln)
     d.ln_eps = LN_EPS
     d.tile = 6  # CG_TILE_128x128_M32
   _autotune_tile(d)
@@ -806,6 +806,7 @@ class _GenWorkspace(object):
                            w0 * nd, 1, w0 * nd, net.w_in.CK, bias=V[1],
                            epilogue=_lib.EPI_LRELU)
     self.f_conv = []
+    self.f_conv_fwd_only = []  # G(z) of a critic update: nothing kept for backward
     self.ln_fused = []
     for i, (lay, ic) in enumerate(zip(net.layers, net.idx_conv)):
       op = net.w_fwd[i]
@@ -823,6 +824,15 @@ class _GenWorkspace(object):
                      yoff_phase_step=1,
                      ln=(V[ic + 2], V[ic + 3], self.h[i + 1], self.mean[i + 1],
                          self.rstd[i + 1]) if fuse else None))
+      self.f_conv_fwd_only.append(
+          _conv_desc(self.h[i], op.buf, dst, B, lay.lin, lay.cinp, k // 2, 1,
+                     net.fwd_offs[0], lay.lin, lay.cout, lay.lout, lay.coutp,
+                     op.CK, y_stride=2, y_off=0, bias=V[ic + 1], nphase=2,
+                     w_phase_stride=op.elems,
+                     off_phase_step=net.fwd_offs[1] - net.fwd_offs[0],
+                     yoff_phase_step=1,
+                     ln=(V[ic + 2], V[ic + 3], self.h[i + 1], None, None))
+          if fuse else self.f_conv[-1])
     self.f_out = _conv_desc(
         self.h[-1], net.w_out.buf, self.fake, B, net.L, net.Cp, 1, 1, 0, net.L,
         net.C, net.L, net.Cp, net.w_out.CK, bias=V[net.idx_out + 1],
@@ -851,16 +861,20 @@ class _GenWorkspace(object):
     self.b_in_wgrad = _wgrad_desc(self.z, self.dy[0], G[0], B, 1, nd, 1,
                                   w0 * nd, 1, 1, 0, nd, w0 * nd)
 
-  def forward(self, z_f32):
-    """z (B, nd) f32 device -> self.fake (B, L, Cp) f32 (first C channels)."""
+  def forward(self, z_f32, keep=True):
+    """z (B, nd) f32 device -> self.fake (B, L, Cp) f32 (first C channels).
+    keep=False: forward only (the fake batch of a critic update) -- the fused
+    LayerNorm launches then skip the pre-activations and row statistics that
+    only backward() reads."""
     net = self.net
+    convs = self.f_conv if keep else self.f_conv_fwd_only
     st = _stream()
     _lib.call('cg_cast_pad', _p(z_f32), _p(self.z), self.B, net.nd, net.nd,
               net.nd, st)
     _run_conv(self.f_in, st)
     V = net.params.views
     for i, (lay, ic) in enumerate(zip(net.layers, net.idx_conv)):
-      _run_conv(self.f_conv[i], st)
+      _run_conv(convs[i], st)
       if net.layer_norm and not self.ln_fused[i]:
         _lib.call('cg_ln_lrelu_fwd', _p(self.ypre[i + 1]), _p(V[ic + 2]),
                   _p(V[ic + 3]), _p(self.h[i + 1]), _p(self.mean[i + 1]),

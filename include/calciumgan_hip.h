@@ -117,7 +117,9 @@ typedef struct cg_conv_desc {
    * Conv1DTranspose, calciumgan.py:68-70 fused into the producing launch):
    * y receives the bf16 pre-activation, ln_h = lrelu(LN(y)), ln_mean / ln_rstd
    * the per-row statistics (indexed like rows of y) cg_ln_lrelu_bwd consumes.
-   * Needs N <= 128, bf16 output and a 128-column tile (cg_tile_shape). */
+   * Needs N <= 128, bf16 output and a 128-column tile (cg_tile_shape).
+   * ln_mean = ln_rstd = NULL: forward only -- neither the statistics nor the
+   * pre-activation y are stored (y may then be any non-NULL pointer). */
   const float* ln_gamma; /* f32 [N] */
   const float* ln_beta;  /* f32 [N] */
   void* ln_h;            /* bf16, geometry of y */
