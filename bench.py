@@ -89,31 +89,36 @@ def algorithmic_bytes_swconv(hp, B):
                  (lay.lin * lay.cinp * 2 if masked else 0)) + \
         k * lay.coutp * lay.cin * 2
 
-  def convT(nb, lay):  # G conv-transpose fwd (two phases)
-    # rows of <= 128 channels: LayerNorm + LeakyReLU fused -- the launch also
-    # writes the activation and the row statistics
-    ln = lay.lout * (lay.coutp * 2 + 8) if (hp.layer_norm and
-                                            lay.cout <= 128) else 0
-    return nb * (lay.lin * lay.cinp * 2 + lay.lout * lay.coutp * 2 + ln) + \
-        k * lay.cinp * lay.cout * 2
+  def convT(nb, lay, keep):  # G conv-transpose fwd (two phases)
+    # rows of <= 128 channels: LayerNorm + LeakyReLU fused -- the launch writes
+    # the activation, and (keep: a backward follows) also the pre-activation
+    # and the row statistics
+    out = lay.lout * lay.coutp * 2
+    if hp.layer_norm and lay.cout <= 128 and keep:
+      out += lay.lout * (lay.coutp * 2 + 8)
+    return nb * (lay.lin * lay.cinp * 2 + out) + k * lay.cinp * lay.cout * 2
 
   def convT_dgrad(nb, lay):
     return nb * (lay.lout * lay.coutp * 2 + lay.lin * lay.cinp * 2) + \
         k * lay.coutp * lay.cin * 2
 
-  g_fwd = B * (nd * 2 + w0 * nd * 2) + nd * w0 * nd * 2
-  g_fwd += sum(convT(B, l) for l in g_l)
   streaming = cp <= 128  # last Dense in cg_dense_rows, not a swconv launch
-  if not streaming:
-    g_fwd += B * L * (cp * 2 + cp * 4) + cp * C * 2
+
+  def g_forward(keep):
+    t = B * (nd * 2 + w0 * nd * 2) + nd * w0 * nd * 2
+    t += sum(convT(B, l, keep) for l in g_l)
+    if not streaming:
+      t += B * L * (cp * 2 + cp * 4) + cp * C * 2
+    return t
+
   g_bwd = B * L * (cp * 2 + cp * 2) + cp * C * 2
   g_bwd += sum(convT_dgrad(B, l) for l in g_l)
   d_fwd = lambda nb: sum(conv(nb, l) for l in d_l)
   fusable = lambda l: 2 * max(1, hp.m) + 1 <= l.lin
-  critic = g_fwd + d_fwd(3 * B) + sum(dgrad(3 * B, l, masked=fusable(l))
+  critic = g_forward(False) + d_fwd(3 * B) + sum(dgrad(3 * B, l, masked=fusable(l))
                                       for l in d_l[1:])
   critic += dgrad(B, d_l[0]) + d_fwd(B)  # x^ input gradient + tangent chain
-  gen = g_fwd + d_fwd(B) + sum(dgrad(B, l, masked=fusable(l))
+  gen = g_forward(True) + d_fwd(B) + sum(dgrad(B, l, masked=fusable(l))
                                for l in d_l[1:]) + \
       dgrad(B, d_l[0]) + g_bwd
   g_launches = 6 if streaming else 7
