@@ -61,6 +61,8 @@ struct ConvArgs {
   float* ln_rstd;
   float ln_eps;
   int narrow;      // last channel chunk packed narrow (cg_pack_desc.narrow_last)
+  int ksplit;      // > 1: blockIdx.y walks its share of the channel chunks
+  long long split_stride;  // f32 elements between the splits' partial outputs
   // output-side phase-shuffle adjoint (see cg_conv_desc.out_shifts)
   const int* out_shifts;
   int out_seg;
@@ -154,6 +156,16 @@ swconv_kernel(ConvArgs a) {
   const int bn = np_i % a.gn;
   const int phase = np_i / a.gn;
   const uint16_t* __restrict__ wp = a.w + (long long)phase * a.w_phase_stride;
+  if (a.ksplit > 1) {
+    // split-K: this workgroup owns channel chunks [z * nchunks, (z+1) * nchunks)
+    // (a.nchunks is the per-split count) and writes f32 partial sums to its
+    // own slice of the workspace; everything below sees a shorter K walk
+    const int z = blockIdx.y;
+    a.x += z * a.nchunks * a.CK;
+    wp += (long long)z * a.nchunks * a.Fp * 8;
+    a.y = reinterpret_cast<float*>(a.y) + z * a.split_stride;
+    if (z != a.ksplit - 1) a.narrow = 0;
+  }
   const int off = a.off + phase * a.off_phase_step;
   const int y_off = a.y_off + phase * a.yoff_phase_step;
   const int m0 = bm * TM;
@@ -691,6 +703,56 @@ swconv_kernel(ConvArgs a) {
   }
 }
 
+// Split-K finishing pass (cg_conv_desc.ksplit): one thread per 8 output
+// channels adds the splits' f32 partial sums, then bias / LeakyReLU / mask,
+// and stores bf16 (channel padding [N, Cy) stays zero).
+struct SplitFinishArgs {
+  const float* ws;
+  int nsplit;
+  long long stride;  // f32 elements per split
+  const float* bias;
+  const uint16_t* mask;
+  uint16_t* y;
+  int N, Cy, epilogue;
+  float alpha;
+  long long total8;
+};
+
+__global__ __launch_bounds__(256) void split_finish_kernel(SplitFinishArgs f) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= f.total8) return;
+  const long long e0 = idx * 8;
+  const int c = (int)(e0 % f.Cy);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < f.nsplit; ++z) {
+    const float* p = f.ws + z * f.stride + e0;
+    s0 += *reinterpret_cast<const f32x4*>(p);
+    s1 += *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (f.bias && c + e < f.N) v[e] += f.bias[c + e];
+  if (f.epilogue == CG_EPI_LRELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], f.alpha * v[e]);
+  } else if (f.epilogue == CG_EPI_MASK) {
+    const uint4 h = *reinterpret_cast<const uint4*>(f.mask + e0);
+    const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint16_t hv = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
+      v[e] *= (bf2f(hv) > 0.f) ? 1.f : f.alpha;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (c + e >= f.N) v[e] = 0.f;
+  *reinterpret_cast<uint4*>(f.y + e0) =
+      make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]),
+                 pack2bf(v[6], v[7]));
+}
+
 // ---------------------------------------------------------------------------
 // weight packing
 // ---------------------------------------------------------------------------
@@ -1065,9 +1127,25 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta;
   a.ln_h = reinterpret_cast<uint16_t*>(d->ln_h);
   a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_eps = d->ln_eps;
+  a.ksplit = d->ksplit > 1 ? d->ksplit : 1;
+  a.split_stride = (long long)d->nB * d->Ly * d->Cy;
+  if (a.ksplit > 1) {
+    if (a.nchunks % a.ksplit || d->out_f32 || d->rowsumsq || d->out_shifts ||
+        (d->epilogue != CG_EPI_NONE && d->epilogue != CG_EPI_LRELU &&
+         d->epilogue != CG_EPI_MASK) ||
+        !d->split_ws || d->split_ws_elems < a.ksplit * a.split_stride)
+      return CG_EINVAL;
+    // the main launch stores raw f32 partial sums; cg_swconv's finishing
+    // launch applies bias and epilogue
+    a.nchunks /= a.ksplit;
+    a.y = d->split_ws;
+    a.bias = nullptr;
+    a.out_f32 = 1;
+    a.epilogue = CG_EPI_NONE;
+  }
   a.narrow = 0;
   if (d->w_narrow_last) {
-    if (R != 2 || !a.pmajor || d->CK != 32 || a.nchunks < 2 || d->taps > 32)
+    if (R != 2 || !a.pmajor || d->CK != 32 || d->Cx / d->CK < 2 || d->taps > 32)
       return CG_EINVAL;
     a.narrow = 1;
   }
@@ -1097,19 +1175,32 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   a.gm = (a.M + TM - 1) / TM;
   a.gn = (d->N + TN - 1) / TN;
   a.gp = d->nphase;
-  dim3 grid((unsigned)(((a.gm + 7) / 8) * 8 * a.gn * a.gp));
+  dim3 grid((unsigned)(((a.gm + 7) / 8) * 8 * a.gn * a.gp), (unsigned)a.ksplit);
   hipStream_t s = (hipStream_t)stream;
-#define CG_DISPATCH(RR, FF, WW, MM, KK)                                   \
-  if (R == RR && tc.mf == FF && tc.wgn == WW && tc.mt == MM && ks == KK) \
-    return launch_swconv<RR, FF, WW, MM, KK>(a, grid, lds, sp, s);
+  int rc = CG_EINVAL;
+#define CG_DISPATCH(RR, FF, WW, MM, KK)                                        \
+  else if (R == RR && tc.mf == FF && tc.wgn == WW && tc.mt == MM && ks == KK) \
+    rc = launch_swconv<RR, FF, WW, MM, KK>(a, grid, lds, sp, s);
 #define CG_DISPATCH_RK(FF, WW, MM)                              \
   CG_DISPATCH(1, FF, WW, MM, 4) CG_DISPATCH(2, FF, WW, MM, 4) \
   CG_DISPATCH(1, FF, WW, MM, 2) CG_DISPATCH(2, FF, WW, MM, 2)
+  if (false) {}
   CG_DISPATCH_RK(16, 1, 4) CG_DISPATCH_RK(16, 1, 1) CG_DISPATCH_RK(16, 1, 2)
   CG_DISPATCH_RK(32, 1, 2) CG_DISPATCH_RK(32, 1, 1)
   CG_DISPATCH_RK(32, 2, 4) CG_DISPATCH_RK(32, 2, 2) CG_DISPATCH_RK(16, 2, 8)
   CG_DISPATCH_RK(16, 2, 4)
 #undef CG_DISPATCH_RK
 #undef CG_DISPATCH
-  return CG_EINVAL;
+  if (rc || a.ksplit == 1) return rc;
+  // split-K finishing launch: y = epi(sum_z ws[z] + bias), bf16
+  SplitFinishArgs f;
+  f.ws = d->split_ws; f.nsplit = a.ksplit; f.stride = a.split_stride;
+  f.bias = d->bias; f.mask = reinterpret_cast<const uint16_t*>(d->mask_src);
+  f.y = reinterpret_cast<uint16_t*>(d->y);
+  f.N = d->N; f.Cy = d->Cy; f.epilogue = d->epilogue; f.alpha = d->alpha;
+  f.total8 = a.split_stride / 8;
+  long long blocks = (f.total8 + 255) / 256;
+  CG_LAUNCH_PROF(CG_FAMILY_SWCONV, split_finish_kernel, dim3((unsigned)blocks),
+                 dim3(256), 0, s, f);
+  CG_LAUNCH_CHECK();
 }

@@ -216,6 +216,23 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
   if small == 0 and stride == 2 and CK <= 32 and Lu % 128 == 0:
     small = 2
   d.tile = small
+  d.ksplit = 0
+  nchunks = Cx // CK
+  if (_SPLIT_K and x.is_cuda and not out_f32 and rowsumsq is None and
+      ln is None and out_shifts is None and nchunks % 2 == 0 and
+      epilogue in (_lib.EPI_NONE, _lib.EPI_LRELU, _lib.EPI_MASK) and
+      nB * Lu * n_tiles_n * nphase <= _SPLIT_K_MAX_TILES * 64):
+    # few output tiles (the tangent chain's single segment): let the tuner try
+    # 2 / 4 workgroups per tile, each over a share of the channel chunks.
+    # Workspaces are shared per size (launches are stream-ordered).
+    smax = 4 if nchunks % 4 == 0 else 2
+    need = smax * nB * Ly * Cy
+    ws = _SPLIT_WS.get(need)
+    if ws is None:
+      ws = _SPLIT_WS[need] = torch.empty(need, dtype=torch.float32,
+                                         device=x.device)
+    d._keep = d._keep + (ws,)
+    d.split_ws, d.split_ws_elems = ws.data_ptr(), need
   if out_shifts is not None:
     sh_t, d.out_seg_size, side_t, d.side_rows = out_shifts
     d._keep = d._keep + (sh_t, side_t)
@@ -233,6 +250,11 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
   return d
 
 
+# Split-K candidates of the tile tuner (CALCIUMGAN_SPLIT_K=0: never): only for
+# launches whose output is at most this many 64x64 tiles
+_SPLIT_K = __import__('os').environ.get('CALCIUMGAN_SPLIT_K', '1') != '0'
+_SPLIT_K_MAX_TILES = 2048
+_SPLIT_WS = {}
 # CALCIUMGAN_FUSE_UNSHUFFLE=0: cg_unshuffle_mask as its own pass after every
 # input-gradient launch of the critic
 _FUSE_UNSHUFFLE = __import__('os').environ.get('CALCIUMGAN_FUSE_UNSHUFFLE',
@@ -311,13 +333,17 @@ def _autotune_tile(d):
       if ok and geo.lds_bytes(d.CK, d.stride, d.taps, d.Lu, tm, tn,
                               mf) <= geo.LDS_BYTES:
         cands.append(small)
-    cands = [(small, ks, 0) for small in cands for ks in (2, 4)]
+    cands = [(small, ks, 0, 1) for small in cands for ks in (2, 4)]
     if d.stride == 2 and d.w_parity_major:
       # split-parity staging: half the LDS window, twice the staging phases
-      cands += [(small, ks, 1) for small, ks, _ in list(cands)
+      cands += [(small, ks, 1, 1) for small, ks, _, _ in list(cands)
                 if geo.lds_bytes(d.CK, 2, d.taps, d.Lu, _lib.TILES[small][0],
                                  _lib.TILES[small][1], _lib.TILES[small][2],
                                  split_parity=True) <= geo.LDS_BYTES]
+    if d.split_ws:
+      nch = d.Cx // d.CK
+      cands += [(small, ks, sp, z) for small, ks, sp, _ in list(cands)
+                for z in (2, 4) if nch % z == 0]
     times = {}
     y_saved = d.y
     scratch = None
@@ -327,10 +353,11 @@ def _autotune_tile(d):
       nbytes = d.nB * d.Ly * d.Cy * (4 if d.out_f32 else 2)
       scratch = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
       d.y = scratch.data_ptr()
-    for small, ks, sp in cands:
+    for small, ks, sp, z in cands:
       d.tile = small
       d.stage_ksteps = ks
       d.split_parity = sp
+      d.ksplit = z
       if lib.cg_swconv(ctypes.byref(d), st) != 0:
         continue
       s = torch.cuda.Event(enable_timing=True)
@@ -340,15 +367,17 @@ def _autotune_tile(d):
         lib.cg_swconv(ctypes.byref(d), st)
       e.record()
       e.synchronize()
-      times[(small, ks, sp)] = s.elapsed_time(e)
+      times[(small, ks, sp, z)] = s.elapsed_time(e)
     d.y = y_saved
     d.split_parity = 0
+    d.ksplit = 0
     del scratch
     if not times:
       return
     best = min(times, key=times.get)
     _TILE_CACHE[key] = best
-  d.tile, d.stage_ksteps, d.split_parity = best
+  d.tile, d.stage_ksteps, d.split_parity = best[:3]
+  d.ksplit = best[3] if len(best) > 3 and d.split_ws else 0
 
 
 # K'-split partial sums of cg_wgrad: plain stores + a reducing launch instead of

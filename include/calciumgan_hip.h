@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 7
+#define CG_ABI_VERSION 8
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -140,6 +140,15 @@ typedef struct cg_conv_desc {
   int out_seg_size;
   void* side;           /* bf16 [nB][side_rows][Cy] */
   int side_rows;        /* >= max |shift| */
+  /* Split-K for launches with few output tiles (the penalty's tangent chain:
+   * one 128-sample segment): ksplit > 1 workgroups share an output tile, each
+   * walking Cx/CK/ksplit channel chunks and storing f32 partial sums to
+   * split_ws[z]; a finishing launch adds them, applies bias / LeakyReLU / mask
+   * and writes the bf16 y.  Needs (Cx/CK) % ksplit == 0, bf16 output,
+   * epilogue NONE / LRELU / MASK, no rowsumsq / out_shifts.  0 or 1: off. */
+  int ksplit;
+  float* split_ws;      /* f32 [ksplit][nB][Ly][Cy] */
+  long long split_ws_elems;
 } cg_conv_desc;
 
 int cg_swconv(const cg_conv_desc* d, void* stream);

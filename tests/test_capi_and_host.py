@@ -34,7 +34,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert hasattr(lib, n), 'missing export ' + n
     assert n in _lib.SIGNATURES, 'no ctypes signature for ' + n
   assert sorted(_lib.SIGNATURES) == names
-  assert lib.cg_abi_version() == 7
+  assert lib.cg_abi_version() == 8
 
 
 def test_packed_elems_host_formula():

@@ -150,6 +150,58 @@ def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp):
                                   ref.numpy())
 
 
+@pytest.mark.parametrize('ksplit', [2, 4])
+@pytest.mark.parametrize('tile', [0, 1, 2, 4, 8])
+@pytest.mark.parametrize('nB,L,Ci,Co,k,epi', [(3, 256, 128, 192, 24, 1),
+                                              (2, 128, 102, 64, 24, 2),
+                                              (4, 64, 256, 320, 24, 0)])
+def test_conv_fwd_split_k(tile, ksplit, nB, L, Ci, Co, k, epi):
+  """cg_conv_desc.ksplit: several workgroups per output tile, each over a share
+  of the channel chunks, f32 partial sums + a finishing launch (bias /
+  LeakyReLU / in-place mask).  Exact on integer data, so identical to the
+  unsplit launch and to the oracle; includes the narrow last chunk (Ci = 102),
+  which only the last split walks."""
+  rng = np.random.RandomState(12)
+  x = H.int_tensor(rng, (nB, L, Ci))
+  W = H.int_tensor(rng, (k, Ci, Co), -2, 2, 0.5)
+  b = H.int_tensor(rng, (Co,), -4, 4)
+  shifts = rng.randint(-2, 3, size=nB).astype(np.int32)
+  pre = O.conv1d_same(_shuffle_batch(x, shifts, 1), W, b if epi == 1 else None,
+                      2)
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  Lo = L // 2
+  pl = geo.same_padding_left(k, 2)
+  ck = nets._ck_for(cip, 2, k, Lo)
+  if (cip // ck) % ksplit:
+    pytest.skip('channel chunks do not divide')
+  op = H.pack(W.to(H.DEV), [(0, 1, Ci * Co, Co, 1)], Ci, Co, cip, ck, k,
+              parity_major=True)
+  y = torch.full((nB, Lo, cop), 7.0, dtype=BF16, device=H.DEV)
+  hmask = None
+  if epi == 2:  # in place: y holds the activations whose sign masks the result
+    hm = torch.tensor(rng.randn(nB, Lo, Co).astype(np.float32))
+    y = H.to_pitch(hm, cop)
+    hmask = hm.to(BF16).float()
+    ref = (pre * torch.where(hmask > 0, 1.0, ALPHA)).to(BF16).float()
+  elif epi == 1:
+    ref = O.leaky_relu(pre).to(BF16).float()
+  else:
+    ref = pre.to(BF16).float()
+  ws = torch.full((ksplit * nB * Lo * cop,), float('nan'), device=H.DEV)
+  d = H.conv_desc(H.to_pitch(x, cip), op.buf, y, nB, L, cip, k, 2, -pl, Lo, Co,
+                  Lo, cop, ck, bias=b.to(H.DEV) if epi == 1 else None,
+                  shifts=torch.tensor(shifts, device=H.DEV), seg_size=1,
+                  epilogue=epi, mask_src=y if epi == 2 else None,
+                  w_parity_major=True, w_narrow_last=op.narrow_last)
+  d.ksplit, d.split_ws, d.split_ws_elems = ksplit, ws.data_ptr(), ws.numel()
+  _force_tile(d, tile, 2, 0)
+  H.sync()
+  got = y.float().cpu()
+  np.testing.assert_array_equal(got[:, :, :Co].numpy(), ref.numpy())
+  if cop > Co:
+    assert float(got[:, :, Co:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('tile,ks', ALL_TILES)
 @pytest.mark.parametrize('nB,L,Ci,Co,k', [(2, 512, 102, 128, 24),
                                           (5, 128, 192, 256, 24)])
