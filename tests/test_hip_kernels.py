@@ -368,9 +368,11 @@ def test_conv_transpose_layernorm_fused(tile, ks, B, L, Ci, Co, k):
   ya, yb = y0.float().cpu().numpy(), y1.float().cpu().numpy()
   np.testing.assert_allclose(yb, ya, rtol=2 ** -7, atol=1e-6)
   assert np.mean(ya != yb) < 1e-3
+  # (a pre-activation that rounds the other way moves its row's mean by one
+  # bf16 ulp / Co)
   np.testing.assert_allclose(m1.cpu().numpy(), m0.cpu().numpy(), rtol=1e-4,
-                             atol=2e-4)
-  np.testing.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=2e-4)
+                             atol=1e-3)
+  np.testing.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=2e-3)
   ha, hb = h0.float().cpu().numpy(), h1.float().cpu().numpy()
   np.testing.assert_allclose(hb, ha, rtol=2 ** -6, atol=2e-3)
   assert np.mean(ha != hb) < 2e-2
