@@ -995,6 +995,9 @@ extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {
   CG_LAUNCH_CHECK();
 }
 
+struct SplitProf { bool on; hipEvent_t start; };
+static SplitProf g_split_prof = {false, nullptr};
+
 template <int R, int MF, int WGN, int MT, int KS, bool UNI, bool SP = false,
           bool LN = false>
 static int launch_swconv1(const ConvArgs& a, dim3 grid, size_t lds,
@@ -1007,6 +1010,14 @@ static int launch_swconv1(const ConvArgs& a, dim3 grid, size_t lds,
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
+  }
+  if (g_split_prof.on) {
+    // split-K launch being timed: cg_swconv holds the event pair; this kernel
+    // carries its start, the finishing launch its stop (one timed launch)
+    hipExtLaunchKernelGGL((swconv_kernel<R, MF, WGN, MT, KS, UNI, SP, LN>), grid,
+                          dim3(256), lds, stream, g_split_prof.start, nullptr, 0,
+                          a);
+    CG_LAUNCH_CHECK();
   }
   CG_LAUNCH_PROF(CG_FAMILY_SWCONV,
                  (swconv_kernel<R, MF, WGN, MT, KS, UNI, SP, LN>), grid,
@@ -1178,6 +1189,11 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   dim3 grid((unsigned)(((a.gm + 7) / 8) * 8 * a.gn * a.gp), (unsigned)a.ksplit);
   hipStream_t s = (hipStream_t)stream;
   int rc = CG_EINVAL;
+  hipEvent_t split_start = nullptr, split_stop = nullptr;
+  const bool split_timed =
+      a.ksplit > 1 && cg_prof_next(CG_FAMILY_SWCONV, &split_start, &split_stop);
+  g_split_prof.on = split_timed;
+  g_split_prof.start = split_start;
 #define CG_DISPATCH(RR, FF, WW, MM, KK)                                        \
   else if (R == RR && tc.mf == FF && tc.wgn == WW && tc.mt == MM && ks == KK) \
     rc = launch_swconv<RR, FF, WW, MM, KK>(a, grid, lds, sp, s);
@@ -1191,6 +1207,7 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   CG_DISPATCH_RK(16, 2, 4)
 #undef CG_DISPATCH_RK
 #undef CG_DISPATCH
+  g_split_prof.on = false;
   if (rc || a.ksplit == 1) return rc;
   // split-K finishing launch: y = epi(sum_z ws[z] + bias), bf16
   SplitFinishArgs f;
@@ -1200,7 +1217,11 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   f.N = d->N; f.Cy = d->Cy; f.epilogue = d->epilogue; f.alpha = d->alpha;
   f.total8 = a.split_stride / 8;
   long long blocks = (f.total8 + 255) / 256;
-  CG_LAUNCH_PROF(CG_FAMILY_SWCONV, split_finish_kernel, dim3((unsigned)blocks),
-                 dim3(256), 0, s, f);
+  if (split_timed)
+    hipExtLaunchKernelGGL(split_finish_kernel, dim3((unsigned)blocks), dim3(256),
+                          0, s, nullptr, split_stop, 0, f);
+  else
+    hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       s, f);
   CG_LAUNCH_CHECK();
 }
