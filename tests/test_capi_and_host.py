@@ -34,7 +34,15 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert hasattr(lib, n), 'missing export ' + n
     assert n in _lib.SIGNATURES, 'no ctypes signature for ' + n
   assert sorted(_lib.SIGNATURES) == names
-  assert lib.cg_abi_version() == 8
+  want = int(re.search(r'#define CG_ABI_VERSION (\d+)', open(HEADER).read()).group(1))
+  assert lib.cg_abi_version() == want
+
+
+def test_graft_entry_build_runs():
+  """The driver's build check: compiles (or finds) every extension, loads the
+  C ABI and checks its version against the header."""
+  import __graft_entry__ as entry
+  entry.build()
 
 
 def test_packed_elems_host_formula():
