@@ -95,8 +95,8 @@ class WGAN_GP(GAN):
     if fake is None:
       fake = st['gws'].forward(z, keep=False)
     _lib.call('cg_interp_pack', nets._p(real), nets._p(fake), nets._p(alpha),
-              nets._p(st['dws'].act[0]), B, lay.lin, lay.cin, lay.cin, lay.cinp,
-              lay.cinp, 0 if real_cached else 1, s)
+              nets._p(st['dws'].act[0]), B, lay.lin, lay.cin, lay.cin,
+              self.generator.net.Cf, lay.cinp, 0 if real_cached else 1, s)
     plan.forward()
     plan.backward_chain()
     n = lay.lin * lay.cinp
@@ -197,7 +197,7 @@ class WGAN_GP(GAN):
     s = nets._stream()
     plan.shifts.copy_(shifts, non_blocking=True)
     _lib.call('cg_cast_pad', nets._p(fake), nets._p(st['dws'].act[0]),
-              B * lay.lin, lay.cin, lay.cinp, lay.cinp, s)
+              B * lay.lin, lay.cin, self.generator.net.Cf, lay.cinp, s)
     plan.forward()
     _lib.call('cg_neg_mean', nets._p(st['dws'].d_out), nets._p(st['gen_loss']),
               B, s)
@@ -208,7 +208,7 @@ class WGAN_GP(GAN):
   def _gen_metrics(self, real):
     """gan.py:32-41 on the fake batch of the generator update."""
     st = self._get_state(real.shape[0])
-    return self.metrics(real, st['gws'].fake, fake_pitch=self.generator.net.Cp)
+    return self.metrics(real, st['gws'].fake, fake_pitch=self.generator.net.Cf)
 
   def _gen_apply(self, real, lr_t_dev=None, metrics=None):
     self.gen_optimizer.update(self.generator, self._sync.grad_scale,
@@ -426,7 +426,7 @@ class WGAN_GP(GAN):
       ], dim=1)
     fake = self._critic_forward(st, real, z, alpha, shifts, 0)
     C = self.generator.net.C
-    metrics = self.metrics(real, fake, fake_pitch=self.generator.net.Cp)
+    metrics = self.metrics(real, fake, fake_pitch=self.generator.net.Cf)
     loss = st['loss'][0].clone()
     return (fake[:, :, :C].clone(), loss[1], loss[0], st['gp'][0].clone(),
             metrics)

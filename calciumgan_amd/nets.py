@@ -794,6 +794,11 @@ class GeneratorNet(object):
                                self.Cp, ck, 1)
     self.w_out_t = PackedOperand(Wo, [(0, 1, 0, 1, self.C)], self.C, self.C,
                                  self.Cp, ck, 1)
+    # the f32 output (B, L, Cf): the streaming Dense writes rows of C rounded
+    # up to 8 channels (102 -> 104: 19 % fewer bytes than the bf16 pitch 128 for
+    # it and for every pass that reads it); the swconv fallback keeps Cp
+    self.streaming_out = self.Cp <= 128 and ck == 32
+    self.Cf = (self.C + 7) // 8 * 8 if self.streaming_out else self.Cp
     self._pack_plan = PackPlan(
         [self.w_in, self.w_out, self.w_out_t] + self.w_fwd + self.w_dgrad,
         device)
@@ -824,7 +829,7 @@ class _GenWorkspace(object):
     self.ypre = [None] + [z(B, l.lout, l.coutp) for l in net.layers]
     self.mean = [None] + [z(B * l.lout, dt=torch.float32) for l in net.layers]
     self.rstd = [None] + [z(B * l.lout, dt=torch.float32) for l in net.layers]
-    self.fake = z(B, net.L, net.Cp, dt=torch.float32)
+    self.fake = z(B, net.L, net.Cf, dt=torch.float32)
     # backward buffers
     self.dz = z(B, net.L, net.Cp)
     self.dh = [z(B, w0, nd)] + [z(B, l.lout, l.coutp) for l in net.layers]
@@ -862,7 +867,9 @@ class _GenWorkspace(object):
                      yoff_phase_step=1,
                      ln=(V[ic + 2], V[ic + 3], self.h[i + 1], None, None))
           if fuse else self.f_conv[-1])
-    self.f_out = _conv_desc(
+    # (fallback for outputs wider than 128 channels; the streaming Dense of
+    # forward() otherwise -- self.fake then has the narrower pitch Cf)
+    self.f_out = None if net.streaming_out else _conv_desc(
         self.h[-1], net.w_out.buf, self.fake, B, net.L, net.Cp, 1, 1, 0, net.L,
         net.C, net.L, net.Cp, net.w_out.CK, bias=V[net.idx_out + 1],
         epilogue=_lib.EPI_SIGMOID if net.normalize else _lib.EPI_NONE,
@@ -891,7 +898,7 @@ class _GenWorkspace(object):
                                   w0 * nd, 1, 1, 0, nd, w0 * nd)
 
   def forward(self, z_f32, keep=True):
-    """z (B, nd) f32 device -> self.fake (B, L, Cp) f32 (first C channels).
+    """z (B, nd) f32 device -> self.fake (B, L, Cf) f32 (first C channels).
     keep=False: forward only (the fake batch of a critic update) -- the fused
     LayerNorm launches then skip the pre-activations and row statistics that
     only backward() reads."""
@@ -909,11 +916,11 @@ class _GenWorkspace(object):
                   _p(V[ic + 3]), _p(self.h[i + 1]), _p(self.mean[i + 1]),
                   _p(self.rstd[i + 1]), self.B * lay.lout, lay.cout, lay.coutp,
                   LN_EPS, LEAKY_ALPHA, st)
-    if net.Cp <= 128 and net.w_out.CK == 32:
+    if net.streaming_out:
       # HBM-bound per-timestep Dense (+ sigmoid): the streaming kernel
       _lib.call('cg_dense_rows', _p(self.h[-1]), _p(net.w_out.buf),
                 _p(V[net.idx_out + 1]), _p(self.fake), self.B * net.L, net.Cp,
-                net.C, net.Cp,
+                net.C, net.Cf,
                 _lib.EPI_SIGMOID if net.normalize else _lib.EPI_NONE, st)
     else:
       _run_conv(self.f_out, st)
@@ -929,7 +936,7 @@ class _GenWorkspace(object):
     rows = self.B * net.L
     if net.normalize:
       _lib.call('cg_sigmoid_bwd', _p(dfake), _p(self.fake), _p(self.dz),
-                rows, net.C, net.Cp, net.Cp, st)
+                rows, net.C, net.Cf, net.Cp, st)
     else:
       self.dz.copy_(dfake.view_as(self.dz))  # linear output: dz = dfake
     _run_wgrad(self.b_out_wgrad, st)
