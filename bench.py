@@ -67,10 +67,13 @@ def algorithmic_flops(hp):
               dense_rows=dense_rows)
 
 
-def algorithmic_bytes_swconv(hp, B):
+def algorithmic_bytes_swconv(hp, B, batched_g=False):
   """Algorithmic HBM bytes of all cg_swconv launches of one train(): every
   launch reads its bf16 source tensor and its packed bf16 weights once and
-  writes its output once (bf16; f32 for the generator output).  Returns
+  writes its output once (bf16; f32 for the generator output).  batched_g:
+  the fake batches of all critic updates come from one generator pass (single
+  rank) -- same activation bytes, the generator's weights read once instead of
+  n_critic times, n_critic - 1 fewer launches per generator layer.  Returns
   (bytes per step, launches per step)."""
   from calciumgan_amd import geometry as geo
   k, n = hp.kernel_size, hp.n_critic
@@ -123,7 +126,14 @@ def algorithmic_bytes_swconv(hp, B):
       dgrad(B, d_l[0]) + g_bwd
   g_launches = 6 if streaming else 7
   launches = n * (g_launches + 5 + 4 + 1 + 5) + (g_launches + 5 + 4 + 1 + 6)
-  return n * critic + gen, launches
+  total = n * critic + gen
+  if batched_g and n > 1:
+    launches -= (n - 1) * g_launches
+    g_weights = nd * w0 * nd * 2 + sum(k * l.cinp * l.cout * 2 for l in g_l)
+    if not streaming:
+      g_weights += cp * C * 2
+    total -= (n - 1) * g_weights
+  return total, launches
 
 
 def cpu_baseline(hp, batch, steps):
@@ -271,7 +281,9 @@ def main():
           '{} steps run right after the timed region ({:.2f} ms/step '
           'eager vs {:.2f} ms/step timed)'.format(
               args.steps, dt_prof / args.steps * 1e3, dt / args.steps * 1e3))
-      ab, alaunch = algorithmic_bytes_swconv(hp, B)
+      from calciumgan_amd.gan.algorithms import wgan_gp as _w
+      ab, alaunch = algorithmic_bytes_swconv(
+          hp, B, batched_g=world == 1 and _w._BATCH_G and not _w._FORCE_SPLIT)
       roofline['algorithmic_hbm_bytes_per_launch'] = ab / alaunch
       pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
       if os.path.exists(pmc):

@@ -37,6 +37,10 @@ from .registry import register
 _GRAPH_WARMUP_CALLS = 2
 # development knob: keep the multi-rank segmentation on a single rank
 _FORCE_SPLIT = os.environ.get('CALCIUMGAN_SPLIT_SEGMENTS', '0') == '1'
+# single rank: one generator pass for the fake batches of all critic updates
+# of a step (CALCIUMGAN_BATCH_G=0: one pass per update, as under data
+# parallelism, where each pass hides the previous update's all-reduce)
+_BATCH_G = os.environ.get('CALCIUMGAN_BATCH_G', '1') != '0'
 
 
 @register('wgan-gp')
@@ -128,6 +132,21 @@ class WGAN_GP(GAN):
     else:
       z = self._to_device(r['z'])
     return st['gws'].forward(z, keep=keep)
+
+  def _critic_generate_all(self, real, rs):
+    """G(z) of ALL critic updates of one train() as one forward-only pass
+    over len(rs) * B samples: the generator does not change between them
+    (wgan_gp.py:84-90 updates only the critic), and the small early layers run
+    far better at 5 B.  Returns one (B, L, Cf) view per update."""
+    B = real.shape[0]
+    n = len(rs)
+    if rs[0] is None or 'shifts_dev' in rs[0]:
+      z = self.get_noise(n * B)
+    else:
+      z = torch.cat([self._to_device(r['z']) for r in rs], 0)
+    ws = self.generator.net.workspace(n * B, forward_only=True)
+    fake = ws.forward(z, keep=False)
+    return [fake[i * B:(i + 1) * B] for i in range(n)]
 
   def _critic_compute(self, real, r=None, slot=0, real_cached=False,
                       fake=None):
@@ -292,6 +311,15 @@ class WGAN_GP(GAN):
     if self._sync.world == 1 and not _FORCE_SPLIT:
       # no collective to cut around: the whole step is one segment (one graph)
       fns = [fn for fn, _, _ in segs]
+      if _BATCH_G and n > 1:
+        # ... and no all-reduce for G(z_i) to hide behind: all critic updates'
+        # fake batches come from ONE generator pass at the start of the step
+        def generate_all():
+          for i, f in enumerate(self._critic_generate_all(
+              real, [rc(i) for i in range(n)])):
+            box[i] = f
+        fns = ([generate_all] + [critic_seg(i, False) for i in range(n)] +
+               [generate('g', rg), gen_seg, metrics_seg, last_seg])
 
       def run_all():
         for fn in fns:

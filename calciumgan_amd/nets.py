@@ -808,19 +808,22 @@ class GeneratorNet(object):
   def repack(self):
     self._pack_plan.run()
 
-  def workspace(self, B):
-    ws = self._ws.get(B)
+  def workspace(self, B, forward_only=False):
+    """forward_only: no backward buffers / descriptors (the batched G(z) of
+    all critic updates of a step)."""
+    ws = self._ws.get((B, forward_only))
     if ws is None:
-      ws = _GenWorkspace(self, B)
-      self._ws[B] = ws
+      ws = _GenWorkspace(self, B, forward_only)
+      self._ws[(B, forward_only)] = ws
     return ws
 
 
 class _GenWorkspace(object):
 
-  def __init__(self, net, B):
+  def __init__(self, net, B, forward_only=False):
     dev = net.device
     self.net, self.B = net, B
+    self.forward_only = forward_only
     z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)
     nd, w0 = net.nd, net.w0
     V = net.params.views
@@ -830,10 +833,10 @@ class _GenWorkspace(object):
     self.mean = [None] + [z(B * l.lout, dt=torch.float32) for l in net.layers]
     self.rstd = [None] + [z(B * l.lout, dt=torch.float32) for l in net.layers]
     self.fake = z(B, net.L, net.Cf, dt=torch.float32)
-    # backward buffers
-    self.dz = z(B, net.L, net.Cp)
-    self.dh = [z(B, w0, nd)] + [z(B, l.lout, l.coutp) for l in net.layers]
-    self.dy = [z(B, 1, w0 * nd)] + [z(B, l.lout, l.coutp) for l in net.layers]
+    if not forward_only:  # backward buffers
+      self.dz = z(B, net.L, net.Cp)
+      self.dh = [z(B, w0, nd)] + [z(B, l.lout, l.coutp) for l in net.layers]
+      self.dy = [z(B, 1, w0 * nd)] + [z(B, l.lout, l.coutp) for l in net.layers]
     k = net.k
     # ---- forward descriptors
     self.f_in = _conv_desc(self.z, net.w_in.buf, self.h[0], B, 1, nd, 1, 1, 0, 1,
@@ -874,6 +877,8 @@ class _GenWorkspace(object):
         net.C, net.L, net.Cp, net.w_out.CK, bias=V[net.idx_out + 1],
         epilogue=_lib.EPI_SIGMOID if net.normalize else _lib.EPI_NONE,
         out_f32=True)
+    if forward_only:
+      return
     # ---- backward descriptors
     G = net.params.grad_views
     self.b_out_dgrad = _conv_desc(self.dz, net.w_out_t.buf, self.dh[-1], B,
