@@ -580,21 +580,25 @@ __global__ void neg_mean_kernel(const float* __restrict__ d_out,
   if (threadIdx.x == 0) out[0] = -(pr[0] + pr[1] + pr[2] + pr[3]) / B;
 }
 
-// column sums: block handles `rows_per_block` rows; thread -> (8-channel group,
-// row lane); LDS reduce then one atomic per channel per block.
+// column sums: block handles `rows_per_block` rows of one slab of up to 2048
+// channels (blockIdx.y); thread -> (8-channel group, row lane); LDS reduce then
+// one atomic per channel per block.
 __global__ __launch_bounds__(kThreads) void colsum_kernel(
     const uint16_t* __restrict__ x, float* __restrict__ out, long long rows,
     int C, int Cp, int rows_per_block) {
-  extern __shared__ float sacc[];  // [Cp]
-  const int groups = Cp / 8;
+  extern __shared__ float sacc[];  // [slab channels]
+  const int c_base = blockIdx.y * (kThreads * 8);
+  const int slab = min(Cp - c_base, kThreads * 8);
+  const int groups = slab / 8;
   const int rlanes = kThreads / groups;  // rows processed concurrently
-  for (int c = threadIdx.x; c < Cp; c += kThreads) sacc[c] = 0.f;
+  for (int c = threadIdx.x; c < slab; c += kThreads) sacc[c] = 0.f;
   __syncthreads();
   const int grp = threadIdx.x % groups;
   const int rl = threadIdx.x / groups;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (rl < rlanes) {
     const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const uint16_t* xg = x + c_base + grp * 8;
     // four rows' loads in flight per thread before the first add
     for (int rr = rl; rr < rows_per_block; rr += 4 * rlanes) {
       uint4 raw[4];
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(kThreads) void colsum_kernel(
       for (int k = 0; k < 4; ++k) {
         const long long row = r0 + rr + k * rlanes;
         raw[k] = (rr + k * rlanes < rows_per_block && row < rows)
-                     ? ldg16(x + row * Cp + grp * 8)
+                     ? ldg16(xg + row * Cp)
                      : make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
@@ -617,7 +621,8 @@ __global__ __launch_bounds__(kThreads) void colsum_kernel(
     for (int e = 0; e < 8; ++e) atomicAdd(&sacc[grp * 8 + e], acc[e]);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += kThreads) atomicAdd(out + c, sacc[c]);
+  for (int c = threadIdx.x; c < slab; c += kThreads)
+    if (c_base + c < C) atomicAdd(out + c_base + c, sacc[c]);
 }
 
 __global__ __launch_bounds__(kThreads) void sigmoid_bwd_kernel(
@@ -987,16 +992,18 @@ extern "C" int cg_neg_mean(const float* d_out, float* out, int B, void* stream) 
 
 extern "C" int cg_colsum(const void* x, float* out, long long rows, int C,
                          int Cp, void* stream) {
-  if (Cp % 8 || Cp / 8 > kThreads || C > Cp) return CG_EINVAL;
+  if (Cp % 8 || C > Cp || rows < 1) return CG_EINVAL;
   // enough rows per block to amortise the LDS/global atomics, still >= ~512
   // blocks on the large activations
   int rows_per_block = 256;
   while (rows_per_block < 4096 && rows / (rows_per_block * 2) >= 512)
     rows_per_block *= 2;
+  const int slabs = (Cp + kThreads * 8 - 1) / (kThreads * 8);
+  const int slab_ch = Cp < kThreads * 8 ? Cp : kThreads * 8;
   hipLaunchKernelGGL(colsum_kernel,
-                     dim3(grid1d(rows, rows_per_block, 1LL << 31)),
-                     dim3(kThreads), Cp * sizeof(float), S_(stream), U16(x), out,
-                     rows, C, Cp, rows_per_block);
+                     dim3(grid1d(rows, rows_per_block, 1LL << 31), slabs),
+                     dim3(kThreads), slab_ch * sizeof(float), S_(stream), U16(x),
+                     out, rows, C, Cp, rows_per_block);
   CG_LAUNCH_CHECK();
 }
 

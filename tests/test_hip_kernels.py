@@ -809,6 +809,15 @@ def test_adam_colsum_sigmoid_lrelu_metrics():
   _lib.call('cg_colsum', H.p(xd), H.p(out), rows, C, cp, H.stream())
   H.sync()
   np.testing.assert_array_equal(out.cpu().numpy(), x[0].sum(0).numpy())
+  # rows wider than one 2048-channel slab (the generator's input Dense bias
+  # gradient at sequence length 8192: 256 * 32 columns), and an odd tail slab
+  for rows_w, cw in ((37, 8192), (300, 2080)):
+    xw = H.int_tensor(rng, (1, rows_w, cw), -3, 3)
+    outw = torch.zeros(cw, device=H.DEV)
+    _lib.call('cg_colsum', H.p(H.to_pitch(xw, cw)), H.p(outw), rows_w, cw, cw,
+              H.stream())
+    H.sync()
+    np.testing.assert_array_equal(outw.cpu().numpy(), xw[0].sum(0).numpy())
   # sigmoid bwd
   fake = torch.tensor(rng.rand(1, rows, C).astype(np.float32))
   dfake = torch.zeros(1, rows, cp)
