@@ -33,7 +33,7 @@ def no_a_staging(s):
 
 
 def no_b_dma(s):
-  return sub(s, '        if (gs + 2 < total_stages) issue_dma(gs + 2);\n', '')
+  return sub(s, '        if (gs + kNBufB - 1 < total_stages) issue_dma(gs + kNBufB - 1);\n', '')
 
 
 def no_barrier(s):
