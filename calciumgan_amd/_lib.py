@@ -85,6 +85,7 @@ class WgradDesc(C.Structure):
 # name -> argtypes (restype is int unless listed in _RESTYPES)
 SIGNATURES = {
     'cg_abi_version': [],
+    'cg_struct_size': [c_i],
     'cg_tile_shape': [c_i, C.POINTER(c_i), C.POINTER(c_i)],
     'cg_profile_enable': [c_i],
     'cg_profile_collect': [C.POINTER(c_f), C.POINTER(c_i), c_i],
@@ -157,6 +158,13 @@ def load():
     fn = getattr(lib, name)  # AttributeError if the symbol is missing
     fn.argtypes = argtypes
     fn.restype = _RESTYPES.get(name, c_i)
+  # the ctypes mirrors of the descriptor structs must match the compiled header
+  for which, cls in enumerate((ConvDesc, PackDesc, WgradDesc)):
+    if lib.cg_struct_size(which) != C.sizeof(cls):
+      raise HipLibraryError(
+          'calciumgan_amd: {} is {} bytes here, {} in {} -- stale build or '
+          'binding (rebuild with `python -m calciumgan_amd.build`)'.format(
+              cls.__name__, C.sizeof(cls), lib.cg_struct_size(which), LIB_PATH))
   _lib = lib
   return lib
 

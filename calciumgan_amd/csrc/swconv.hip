@@ -852,6 +852,15 @@ inline int ilog2(int v) {
 
 extern "C" int cg_abi_version(void) { return CG_ABI_VERSION; }
 
+extern "C" int cg_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(cg_conv_desc);
+    case 1: return (int)sizeof(cg_pack_desc);
+    case 2: return (int)sizeof(cg_wgrad_desc);
+    default: return -1;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // launch profiler (process-wide, eager launches only; see cg_common.h)
 // ---------------------------------------------------------------------------

@@ -52,6 +52,10 @@ extern "C" {
 #define CG_NUM_TILES 9
 
 int cg_abi_version(void);
+/* sizeof() of the descriptor structs as this library was compiled
+ * (which: 0 cg_conv_desc, 1 cg_pack_desc, 2 cg_wgrad_desc; else -1): a binding
+ * checks its own struct layout against it before the first launch. */
+int cg_struct_size(int which);
 /* rows / columns of a CG_TILE_* value (host helper; CG_EINVAL if unknown) */
 int cg_tile_shape(int tile, int* rows, int* cols);
 

@@ -45,6 +45,15 @@ def test_graft_entry_build_runs():
   entry.build()
 
 
+def test_descriptor_layouts_match_library():
+  """ctypes mirrors vs the compiled structs (also enforced by _lib.load)."""
+  import ctypes
+  lib = _lib.load()
+  for which, cls in enumerate((_lib.ConvDesc, _lib.PackDesc, _lib.WgradDesc)):
+    assert lib.cg_struct_size(which) == ctypes.sizeof(cls), cls.__name__
+  assert lib.cg_struct_size(3) == -1
+
+
 def test_packed_elems_host_formula():
   lib = _lib.load()
   # N rows padded to 128, K padded to 16 groups of 8 per channel chunk
