@@ -247,6 +247,30 @@ def test_train_tracks_oracle_over_steps():
       assert np.linalg.norm(w_h - w_o.numpy()) / mv < 0.25
 
 
+def test_single_pass_generator_matches_per_update_passes(monkeypatch):
+  """One train() with the fake batches of all critic updates from ONE
+  forward-only generator pass (the single-rank schedule) against the same call
+  with one pass per update (the data-parallel schedule): same weights, same
+  injected randomness -> same losses and the same weight updates up to the
+  bf16 rounding of differently tiled launches."""
+  from calciumgan_amd.gan.algorithms import wgan_gp
+  outs = []
+  for batched in (True, False):
+    monkeypatch.setattr(wgan_gp, '_BATCH_G', batched)
+    hp, gen, dis, gan, real, B = _build('mid')
+    rand = O.draw_randomness(hp, B, seed=77)
+    got = gan.train(real, rand)
+    torch.cuda.synchronize()
+    outs.append(([float(got[0]), float(got[1]), float(got[2])],
+                 [w.copy() for w in dis.get_weights()],
+                 [w.copy() for w in gen.get_weights()]))
+  (la, da, ga), (lb, db, gb) = outs
+  np.testing.assert_allclose(la, lb, rtol=2e-3, atol=2e-4)
+  for wa, wb in zip(da + ga, db + gb):
+    # Adam's first steps move every weight by ~lr: compare the movement
+    assert np.abs(wa - wb).max() <= 2.5e-4
+
+
 def test_train_dynamics_follow_f32_oracle():
   """Twenty train() calls (100 critic + 20 generator Adam updates) at the cfg1
   layer shapes on injected randomness, against the plain f32 oracle: the bf16
