@@ -255,6 +255,14 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
   dt = float(t.item())
 
+  # the workload label follows the arguments: only BASELINE.json configs[1]
+  # shapes are called cfg2
+  default_workload = (args.seq_len, args.neurons, args.num_units, args.m,
+                      B) == (2048, 102, 64, 10, 128)
+  cfg_name = 'cfg2' if default_workload else (
+      'cfg1 shapes' if (args.seq_len, args.neurons) == (256, 16) else
+      'cfg5 shapes' if (args.seq_len, args.neurons) == (8192, 512) else
+      'custom shapes (not a BASELINE.json config)')
   if rank == 0:
     fl = algorithmic_flops(hp)
     value = world * B * args.steps / dt
@@ -285,14 +293,18 @@ def main():
       ab, alaunch = algorithmic_bytes_swconv(
           hp, B, batched_g=world == 1 and _w._BATCH_G and not _w._FORCE_SPLIT)
       roofline['algorithmic_hbm_bytes_per_launch'] = ab / alaunch
-      pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-      if os.path.exists(pmc):
+      import glob
+      pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles',
+                                           'r??_pmc_traffic.json')))
+      if pmcs and default_workload:
         # HBM bytes per launch from rocprofv3 PMC passes of this same command
         # (tools/pmc_traffic.sh: FETCH_SIZE x2 per the gfx950 correction +
-        # WRITE_SIZE, separate passes); committed measurement, not live
-        t = json.load(open(pmc)).get('swconv', {})
-        roofline['traffic'] = t.get('hbm_bytes_per_launch')
-        roofline['traffic_source'] = 'profiles/r01_pmc_traffic.json'
+        # WRITE_SIZE, separate passes).  A committed measurement, not a live
+        # one: the file names the commit its kernels were built from
+        pj = json.load(open(pmcs[-1]))
+        roofline['traffic'] = pj.get('swconv', {}).get('hbm_bytes_per_launch')
+        roofline['traffic_source'] = 'profiles/' + os.path.basename(pmcs[-1])
+        roofline['traffic_measured_at_commit'] = pj.get('commit')
       if 'wgrad' in fam:
         wsec, wcnt = fam['wgrad']
         wfl = fl['wgrad'] * B * args.steps
@@ -315,11 +327,11 @@ def main():
         'dtype': 'bf16',
         'data': 'synthetic',
         'config': {
-            'workload': 'cfg2: dichotomised-Gaussian sl{} calcium signals, {} '
+            'workload': '{}: dichotomised-Gaussian sl{} calcium signals, {} '
                         'neurons, batch {}/GPU, calciumgan num_units {} k 24 s 2 '
                         'm {} layer_norm, wgan-gp n_critic 5 lambda 10, Keras '
-                        'Adam 1e-4'.format(args.seq_len, args.neurons, B,
-                                           args.num_units, args.m),
+                        'Adam 1e-4'.format(cfg_name, args.seq_len, args.neurons,
+                                           B, args.num_units, args.m),
             'global_batch': world * B,
             'seq_len': args.seq_len,
             'parallelism': 'dp{}'.format(world),

@@ -18,6 +18,15 @@ TILES = {0: (256, 64, 16), 1: (64, 64, 16), 2: (128, 64, 16),
          3: (256, 64, 32), 4: (128, 64, 32), 5: (256, 128, 32),
          6: (128, 128, 32), 7: (256, 128, 16),
          8: (128, 128, 16)}
+# CG_TILE_SWP_*: value -> (rows, cols); swconv_swp.hip, two waves per SIMD
+SWP_TILES = {9: (512, 64), 10: (256, 64), 11: (256, 128), 12: (128, 128),
+             13: (128, 256)}
+
+
+def tile_shape(tile):
+  """(rows, cols) of any CG_TILE_* value."""
+  return TILES[tile][:2] if tile in TILES else SWP_TILES[tile]
+
 
 c_vp = C.c_void_p
 c_i = C.c_int
@@ -90,6 +99,7 @@ SIGNATURES = {
     'cg_profile_enable': [c_i],
     'cg_profile_collect': [C.POINTER(c_f), C.POINTER(c_i), c_i],
     'cg_swconv': [C.POINTER(ConvDesc), c_vp],
+    'cg_swconv_check': [C.POINTER(ConvDesc)],
     'cg_dense_rows': [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_vp],
     'cg_packed_elems': [c_i, c_i, c_i, c_i],
     'cg_pack_weights': [C.POINTER(PackDesc), c_vp],

@@ -11,8 +11,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libcalciumgan_hip.so')
-SOURCES = ['swconv.hip', 'wgrad.hip', 'pointwise.hip', 'dense_rows.hip']
-HEADERS = ['cg_common.h', os.path.join('..', '..', 'include',
+SOURCES = ['swconv.hip', 'swconv_swp.hip', 'wgrad.hip', 'pointwise.hip',
+           'dense_rows.hip']
+HEADERS = ['cg_common.h', 'swconv_args.h', os.path.join('..', '..', 'include',
                                        'calciumgan_hip.h')]
 
 

@@ -28,47 +28,10 @@
 #include <vector>
 
 #include "cg_common.h"
+#include "swconv_args.h"
 
 namespace {
 
-struct ConvArgs {
-  const uint16_t* x;
-  const uint16_t* w;
-  void* y;
-  const float* bias;
-  const uint16_t* mask;
-  const int* shifts;
-  float* rowsumsq;
-  int nB, Lx, Cx, seg_size;
-  int taps, off, Lu, M;
-  int N, Ly, Cy, y_stride, y_off;
-  int CK, c8, nchunks, Fp, nstages;
-  long long Kpack;
-  int pitchA, S, log2S, nseg, WR, ldsA_elems;
-  int epilogue, out_f32;
-  float alpha;
-  float inv_c8;
-  int log2c8;  // log2(c8) when c8 is a power of two, else -1
-  long long w_phase_stride;
-  int off_phase_step, yoff_phase_step;
-  int gm, gn, gp;  // logical grid: row tiles, column tiles, phases
-  int pmajor;      // stride 2: weights packed even taps first, then odd taps
-  // CG_EPI_LN_LRELU (128-column tiles, N <= 128)
-  const float* ln_gamma;
-  const float* ln_beta;
-  uint16_t* ln_h;
-  float* ln_mean;
-  float* ln_rstd;
-  float ln_eps;
-  int narrow;      // last channel chunk packed narrow (cg_pack_desc.narrow_last)
-  int ksplit;      // > 1: blockIdx.y walks its share of the channel chunks
-  long long split_stride;  // f32 elements between the splits' partial outputs
-  // output-side phase-shuffle adjoint (see cg_conv_desc.out_shifts)
-  const int* out_shifts;
-  int out_seg;
-  uint16_t* side;
-  int side_rows;
-};
 
 // LDS row pitches, 16x16x32: 2*odd 16-byte slots: with the MFMA operand map
 // (lane -> row l&15, k-group l>>4) and ds_read_b128's lane groups
@@ -1006,11 +969,14 @@ extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {
 
 struct SplitProf { bool on; hipEvent_t start; };
 static SplitProf g_split_prof = {false, nullptr};
+// cg_swconv_check: walk the whole validation + dispatch path without launching
+static bool g_dry_run = false;
 
 template <int R, int MF, int WGN, int MT, int KS, bool UNI, bool SP = false,
           bool LN = false>
 static int launch_swconv1(const ConvArgs& a, dim3 grid, size_t lds,
                           hipStream_t stream) {
+  if (g_dry_run) return 0;  // this instantiation exists: the launch is valid
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
@@ -1058,28 +1024,48 @@ static int launch_swconv(const ConvArgs& a, dim3 grid, size_t lds, bool sp,
 }
 
 // cg_conv_desc.tile -> (MFMA rows, waves along N, subtiles per wave)
-struct TileCfg { int mf, wgn, mt; };
+// (swp_wm > 0: a software-pipelined tile of swconv_swp.hip: swp_wm x wgn waves,
+// mt 16-row subtiles per wave)
+struct TileCfg { int mf, wgn, mt, swp_wm; };
 static const TileCfg kTileCfgs[CG_NUM_TILES] = {
-    {16, 1, 4},  // CG_TILE_256x64
-    {16, 1, 1},  // CG_TILE_64x64
-    {16, 1, 2},  // CG_TILE_128x64
-    {32, 1, 2},  // CG_TILE_256x64_M32
-    {32, 1, 1},  // CG_TILE_128x64_M32
-    {32, 2, 4},  // CG_TILE_256x128_M32
-    {32, 2, 2},  // CG_TILE_128x128_M32
-    {16, 2, 8},  // CG_TILE_256x128
-    {16, 2, 4},  // CG_TILE_128x128
+    {16, 1, 4, 0},  // CG_TILE_256x64
+    {16, 1, 1, 0},  // CG_TILE_64x64
+    {16, 1, 2, 0},  // CG_TILE_128x64
+    {32, 1, 2, 0},  // CG_TILE_256x64_M32
+    {32, 1, 1, 0},  // CG_TILE_128x64_M32
+    {32, 2, 4, 0},  // CG_TILE_256x128_M32
+    {32, 2, 2, 0},  // CG_TILE_128x128_M32
+    {16, 2, 8, 0},  // CG_TILE_256x128
+    {16, 2, 4, 0},  // CG_TILE_128x128
+    {16, 1, 4, 8},  // CG_TILE_SWP_512x64
+    {16, 1, 4, 4},  // CG_TILE_SWP_256x64
+    {16, 2, 4, 4},  // CG_TILE_SWP_256x128
+    {16, 2, 4, 2},  // CG_TILE_SWP_128x128
+    {16, 4, 4, 2},  // CG_TILE_SWP_128x256
 };
 
 extern "C" int cg_tile_shape(int tile, int* rows, int* cols) {
   if (tile < 0 || tile >= CG_NUM_TILES) return CG_EINVAL;
   const TileCfg& t = kTileCfgs[tile];
-  if (rows) *rows = (4 / t.wgn) * t.mt * t.mf;
+  if (rows) *rows = t.swp_wm ? t.swp_wm * t.mt * 16 : (4 / t.wgn) * t.mt * t.mf;
   if (cols) *cols = 64 * t.wgn;
   return 0;
 }
 
+static int swconv_run(const cg_conv_desc* d, void* stream);
+
 extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
+  return swconv_run(d, stream);
+}
+
+extern "C" int cg_swconv_check(const cg_conv_desc* d) {
+  g_dry_run = true;
+  const int rc = swconv_run(d, nullptr);
+  g_dry_run = false;
+  return rc;
+}
+
+static int swconv_run(const cg_conv_desc* d, void* stream) {
   if (!d || !d->x || !d->w || !d->y) return CG_EINVAL;
   if (d->stride != 1 && d->stride != 2) return CG_EINVAL;
   if (d->stride == 2 && (d->taps & 1)) return CG_EINVAL;
@@ -1101,7 +1087,7 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
       (tc.wgn != 2 || d->N > 128 || d->out_f32 || d->rowsumsq || !d->ln_gamma ||
        !d->ln_beta || !d->ln_h || (!d->ln_mean != !d->ln_rstd)))
     return CG_EINVAL;
-  const int TM = (4 / tc.wgn) * tc.mt * tc.mf;
+  const int TM = tc.swp_wm ? tc.swp_wm * tc.mt * 16 : (4 / tc.wgn) * tc.mt * tc.mf;
   const int TN = 64 * tc.wgn;
   if (tc.mf == 32 && (d->CK / 8) % 4) return CG_EINVAL;  // uniform K walk only
   int S;
@@ -1174,6 +1160,16 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   a.w_phase_stride = d->w_phase_stride;
   a.off_phase_step = d->off_phase_step;
   a.yoff_phase_step = d->yoff_phase_step;
+  if (tc.swp_wm) {
+    // software-pipelined tile: its own LDS plan and launch (swconv_swp.hip;
+    // inherently one parity at a time: split_parity is not consulted)
+    if (a.Fp != d->taps * a.c8) return CG_EINVAL;
+    a.gm = (a.M + TM - 1) / TM;
+    a.gn = (d->N + TN - 1) / TN;
+    a.gp = d->nphase;
+    return swconv_swp_launch(a, R, tc.swp_wm, tc.wgn, tc.mt, a.ksplit, g_dry_run,
+                             (hipStream_t)stream);
+  }
   size_t ldsA_bytes = (size_t)a.ldsA_elems * 2;
   if (ldsA_bytes < (size_t)kScratchBytes) ldsA_bytes = kScratchBytes;
   ldsA_bytes = (ldsA_bytes + 15) / 16 * 16;
@@ -1200,7 +1196,8 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
   int rc = CG_EINVAL;
   hipEvent_t split_start = nullptr, split_stop = nullptr;
   const bool split_timed =
-      a.ksplit > 1 && cg_prof_next(CG_FAMILY_SWCONV, &split_start, &split_stop);
+      !g_dry_run && a.ksplit > 1 &&
+      cg_prof_next(CG_FAMILY_SWCONV, &split_start, &split_stop);
   g_split_prof.on = split_timed;
   g_split_prof.start = split_start;
 #define CG_DISPATCH(RR, FF, WW, MM, KK)                                        \
@@ -1217,7 +1214,7 @@ extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
 #undef CG_DISPATCH_RK
 #undef CG_DISPATCH
   g_split_prof.on = false;
-  if (rc || a.ksplit == 1) return rc;
+  if (rc || a.ksplit == 1 || g_dry_run) return rc;
   // split-K finishing launch: y = epi(sum_z ws[z] + bias), bf16
   SplitFinishArgs f;
   f.ws = d->split_ws; f.nsplit = a.ksplit; f.stride = a.split_stride;

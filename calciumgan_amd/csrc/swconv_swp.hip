@@ -1,0 +1,577 @@
+// Software-pipelined tiles of the sliding-window convolution (cg_swconv,
+// CG_TILE_SWP_*).
+//
+// Same contraction, operand packing and epilogues as swconv.hip; what differs is
+// how a wave spends its time.  The tile kernels of swconv.hip run a serial
+// chain per weight stage (wait DMA, barrier, read fragments, wait LDS, MFMA) at
+// three waves per SIMD and rely on the co-resident workgroups to overlap each
+// other; their register budget (<= 168) has no room for a second fragment set.
+// Here a wave owns half a SIMD's registers (two waves per SIMD: one 8-wave
+// workgroup, or two 4-wave workgroups, per CU) and pipelines itself:
+//
+//   * fragments are double-buffered at K-step granularity: the ds_reads of
+//     K-step k+1 are issued BEFORE the MFMAs of K-step k, so LDS latency, the
+//     per-stage barrier and the DMA waits sit in the shadow of 16-32 queued
+//     MFMAs instead of in front of them;
+//   * every global -> LDS byte moves by LDS-DMA (global_load_lds_dwordx4), the
+//     source window included: a window row of one 32-channel chunk is 64 B, a
+//     DMA piece 16 rows; rows cannot be padded (the DMA writes lane-linear), so
+//     the four 16-byte chunks of a row are XOR-swizzled by bit 2 of the row
+//     (slot = chunk ^ 2*((row >> 2) & 1)): conflict-free ds_read_b128 for the
+//     16x16x32 A operand at every tap offset.  Zero padding of 'same' and rows
+//     past the batch come from a 64-byte zero page; the PhaseShuffle gather is
+//     the per-lane source address;
+//   * a stride-2 window is walked one source-row parity at a time (the packed
+//     operand is parity-major), so stride 1 and stride 2 share one loop: a PASS
+//     = (channel chunk, parity) = taps/stride taps over a (rows + taps/stride
+//     - 1)-row window.  Windows are double-buffered across passes: the pieces of
+//     pass p+1 are issued during the stages of pass p and retired by counted
+//     vmcnt two stages later (never in the iteration that issues them);
+//   * weight ring: 3 slots of 64-deep stages.  In the second half of stage s
+//     (after the barrier that publishes stage s+1 and frees slot s) the DMA of
+//     stage s+3 is issued into slot s; it has two whole stages to land.
+#include <type_traits>
+
+#include "swconv_args.h"
+
+namespace {
+
+// source of padding rows (a __device__ array is zero-initialised); kernels get
+// its address as an argument (in-kernel it would be a GOT load per use)
+__device__ __attribute__((aligned(64))) uint4 g_zero_page[4];
+
+struct SwpArgs {
+  ConvArgs c;
+  int tpp;           // taps per pass (taps / stride)
+  int WRs;           // window rows per segment: S + tpp - 1
+  int wrows;         // nseg * WRs
+  int npa;           // 1 KiB DMA pieces per window
+  int apw;           // window pieces per wave per issuing stage
+  int abytes;        // bytes per window buffer
+  int npass;         // (nchunks - narrow) * stride + narrow
+  int nst;           // weight stages per full pass (tpp / 2)
+  int total_stages;
+  int npad_rows;     // rows of the packed operand (N rounded up to 128)
+  const unsigned char* zero;  // 64 zero bytes
+  float inv_WRs;
+};
+
+constexpr int kSwpScrPitch = 68;  // f32 epilogue scratch pitch
+constexpr int kSwpRing = 3;       // weight ring depth
+// fragment reads spread one per two MFMAs by sched_group_barrier (measured
+// slower than hipcc's own "all reads, then the MFMAs" order on 9 of 12 cfg2
+// geometries, up to +35 % on the first critic layer; kept for A/B runs)
+#ifndef CG_SWP_INTERLEAVE
+#define CG_SWP_INTERLEAVE 0
+#endif
+constexpr bool kSwpInterleave = CG_SWP_INTERLEAVE != 0;
+
+__device__ __forceinline__ int sw64(int byte) {
+  // XOR-swizzle of a byte offset into a window of 64-byte rows: row bit 2
+  // (address bit 8) flips chunk bit 1 (address bit 5)
+  return byte ^ ((byte >> 3) & 32);
+}
+
+// A compiler-visible use of fragments that were read a whole MFMA block ago:
+// hipcc places its s_waitcnt lgkmcnt HERE (nothing newer is in flight: precise
+// and free) instead of in front of their first MFMA, which by then sits behind
+// the next K-step's freshly issued reads (lgkmcnt(0) there stalls on those).
+template <int N>
+__device__ __forceinline__ void landed(const bf16x8 (&f)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" ::"v"(f[i]));
+}
+
+// R: source stride.  WM x WN waves (4 or 8); wave tile (16 * MT) x 64.
+template <int R, int WM, int WN, int MT>
+__global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) {
+  static_assert(WM * WN == 4 || WM * WN == 8, "one or two waves per SIMD");
+  const ConvArgs& a = pa.c;
+  constexpr int NW = WM * WN;
+  constexpr int NT = 4;
+  constexpr int KS = 2;                   // MFMA K-steps per weight stage
+  constexpr int TM = WM * MT * 16;
+  constexpr int TN = WN * 64;
+  constexpr int kRowB = KS * 32;          // bf16 per weight row of a ring slot
+  constexpr int kBufB = TN * kRowB;       // elements per ring slot
+  constexpr int NBW = TN / 8 / NW;        // weight DMA pieces per wave per stage
+  static_assert(NBW >= 1, "at least one weight piece per wave and stage");
+  // window pieces per wave (windows of at most TM + 8 * 11 rows: nseg <= 8)
+  constexpr int KPW = (TM / 16 + 6 + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ldsA = smem;
+  uint16_t* ldsB = reinterpret_cast<uint16_t*>(smem + 2 * pa.abytes);
+  int* sh_lds = reinterpret_cast<int*>(smem + 2 * pa.abytes + kSwpRing * kBufB * 2);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  // (readfirstlane: the compiler then keeps everything derived from the wave
+  // id in scalar registers and branches on it without exec masks)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+  const int rM = lane & 15;
+  const int g = lane >> 4;
+  // XCD-aware mapping (as swconv_kernel): the workgroups that share one row
+  // tile's source window get linear ids congruent mod 8
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7;
+  const int jq = lin >> 3;
+  const int gnp = a.gn * a.gp;
+  const int np_i = jq % gnp;
+  const int bm = (jq / gnp) * 8 + xcd;
+  if (bm >= a.gm) return;
+  const int bn = np_i % a.gn;
+  const int phase = np_i / a.gn;
+  const uint16_t* __restrict__ wp = a.w + (long long)phase * a.w_phase_stride;
+  const int off = a.off + phase * a.off_phase_step;
+  const int y_off = a.y_off + phase * a.yoff_phase_step;
+  const int m0 = bm * TM;
+  const int n0 = bn * TN;
+  const int b0 = m0 / a.Lu;               // first sample of the tile
+  const int u00 = m0 - b0 * a.Lu;         // its first output row (nseg == 1)
+
+  // per-sample phase shifts of the tile's segments
+  if (a.shifts != nullptr && tid < a.nseg) {
+    const int b = b0 + tid;
+    sh_lds[tid] = b < a.nB ? a.shifts[b / a.seg_size] : 0;
+  }
+  __syncthreads();
+
+  // ---- window pieces ---------------------------------------------------------
+  // piece j of the window of pass p -> buffer p & 1, bytes [j KiB, (j+1) KiB):
+  // lane L lands on (row 16 j + L/4, slot L & 3) and fetches the chunk that
+  // slot holds after the swizzle.  Wave w owns pieces j = k NW + w; the source
+  // address of (k, source-row parity) at channel chunk 0 is computed ONCE here
+  // (per-lane 64-bit pointers; the hot loop only adds the chunk offset), with
+  // the zero page standing in for padding rows and rows past the batch.
+  const int pslot = lane & 3;
+  const int full_passes = (a.nchunks - (a.narrow ? 1 : 0)) * R;
+  // (kept as 32-bit offsets from x in 16-byte units, ~0 = zero page: half the
+  // registers of 64-bit pointers, and nothing for the compiler to hoist)
+  uint32_t aoff[KPW][R];
+  int aq[KPW];          // logical 16-byte chunk this lane fetches
+#pragma unroll
+  for (int k = 0; k < KPW; ++k) {
+    const int row = (k * NW + wave) * 16 + (lane >> 2);
+    const int q = pslot ^ (((row >> 2) & 1) << 1);
+    aq[k] = q;
+    int seg = 0;
+    if (a.nseg > 1) seg = __float2int_rz(((float)row + 0.5f) * pa.inv_WRs);
+    const int wr = row - seg * pa.WRs;
+    const int b = b0 + seg;
+    const int u0 = a.nseg > 1 ? 0 : u00;
+    const int sft = a.shifts != nullptr && seg < a.nseg ? sh_lds[seg] : 0;
+#pragma unroll
+    for (int par = 0; par < R; ++par) {
+      uint32_t o = ~0u;
+      if (row < pa.wrows && b < a.nB) {
+        int srow = R * (u0 + wr) + off + par;
+        if (srow >= 0 && srow < a.Lx) {
+          if (a.shifts) srow = shuffle_src(srow, sft, a.Lx);
+          o = (uint32_t)((((long long)b * a.Lx + srow) * a.Cx + q * 8) >> 3);
+        }
+      }
+      aoff[k][par] = o;
+    }
+  }
+  const unsigned char* xbytes = reinterpret_cast<const unsigned char*>(a.x);
+  // issue slot k of pass p (k compile-time: the offset arrays stay in registers)
+  auto issue_a_piece = [&](int p, int k, uint32_t o0, uint32_t o1, int q) {
+    uint32_t o;
+    int add;
+    if (p < full_passes) {
+      const int cc = R == 2 ? (p >> 1) : p;
+      o = (R == 2 && (p & 1)) ? o1 : o0;
+      add = cc * 64;
+    } else {
+      // narrow last chunk: chunk q of a row = the first 8-channel group of
+      // source-row parity q (q < 2; the rest of the row is never read)
+      o = q >= 2 ? ~0u : ((q & 1) ? o1 : o0);
+      add = (a.nchunks - 1) * 64 - q * 16;
+    }
+    // (opaque to LICM: hoisted out of the stage loop, the 64-bit addresses of
+    // all slots would sit in registers for a whole pass)
+    asm volatile("" : "+v"(o));
+    const unsigned char* src =
+        o == ~0u ? pa.zero : xbytes + ((unsigned long long)o << 4) + add;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)src,
+        (__attribute__((address_space(3))) void*)(ldsA + (p & 1) * pa.abytes +
+                                                  (k * NW + wave) * 1024),
+        16, 0, 0);
+  };
+  // pieces k in [k0, k1) of pass p; returns how many were issued
+  auto issue_a_range = [&](int p, int k0, int k1) {
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < KPW; ++k)
+      if (k >= k0 && k < k1 && (k * NW + wave) < pa.npa) {
+        issue_a_piece(p, k, aoff[k][0], aoff[k][R - 1], aq[k]);
+        ++n;
+      }
+    return n;
+  };
+  // ---- weight stages ---------------------------------------------------------
+  // wave w issues pieces w*NBW + i of a stage: lane L lands at slot byte
+  // piece*1024 + L*16 = (row, chunk slot c') and fetches chunk c' ^ swz(row)
+  const uint16_t* dsrc[NBW];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    const int pe = ((wave * NBW + i) * 1024 + lane * 16) / 2;  // element offset
+    int row = pe / kRowB;
+    const int cs = (pe % kRowB) / 8;
+    const int c = cs ^ ((row >> 1) & 7);
+    row += n0;
+    if (row >= pa.npad_rows) row = pa.npad_rows - 1;  // columns past N: unused
+    dsrc[i] = wp + (long long)row * a.Kpack + c * 8;
+  }
+  auto issue_b = [&](int gs) {
+    uint16_t* slot = ldsB + (gs % kSwpRing) * kBufB;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(dsrc[i] +
+                                                          (long long)gs * (KS * 32)),
+          (__attribute__((address_space(3))) void*)(slot + (wave * NBW + i) * 512),
+          16, 0, 0);
+  };
+
+  // ---- fragment addresses ----------------------------------------------------
+  // window byte offset of (first tile row of this lane, k-group g), tap 0,
+  // unswizzled.  A wave's 16 MT rows lie in ONE segment (S >= 16 MT, checked on
+  // the host), so subtile mt is +mt KiB: the swizzle (bit 5 from bit 8) is
+  // computed once per tap and the subtiles are immediate offsets
+  int rowb0;
+  {
+    const int i = wm * MT * 16 + rM;
+    const int seg = i >> a.log2S;
+    const int ui = i & (a.S - 1);
+    rowb0 = (seg * pa.WRs + ui) * 64 + g * 16;
+  }
+  const int swzB = (rM >> 1) & 7;
+  int boff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    boff[ks] = (wn * 64 + rM) * kRowB + (((4 * ks + g) ^ swzB) * 8);
+  const int half_taps = a.taps >> 1;
+
+  // fragments of K-step ks of stage s (global index gs) of pass p
+  auto read_frags = [&](bf16x8(&af)[MT], bf16x8(&bf)[NT], int p, int s, int gs,
+                        int ks) {
+    const uint16_t* curB = ldsB + (gs % kSwpRing) * kBufB;
+    const unsigned char* abuf = ldsA + (p & 1) * pa.abytes;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      bf[nt] = *reinterpret_cast<const bf16x8*>(curB + nt * 16 * kRowB +
+                                                (ks ? boff[1] : boff[0]));
+    if (p < full_passes) {
+      const int tapoff = (s * KS + ks) * 64;  // one tap per K-step
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        af[mt] = *reinterpret_cast<const bf16x8*>(
+            abuf + sw64(rowb0 + mt * 1024 + tapoff));
+    } else {
+      // narrow chunk: stage s -> parity s >> 1, K-step (s & 1) * 2 + ks; its
+      // four k-groups are four consecutive taps of that parity over the same 8
+      // channels (chunk slot = parity); taps past taps/2 carry zero weights
+      // (row clamped: LDS may hold anything finite)
+      const int par = s >> 1;
+      int idx = 4 * ((s & 1) * 2 + ks) + g;
+      idx = idx < half_taps ? idx : half_taps - 1;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        af[mt] = *reinterpret_cast<const bf16x8*>(
+            abuf + sw64(rowb0 + mt * 1024 - g * 16 + idx * 64 + par * 16));
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mfma_step = [&](const bf16x8(&af)[MT], const bf16x8(&bf)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[nt],
+                                                              acc[mt][nt], 0, 0, 0);
+  };
+
+  // scheduling pattern of a half stage: the MT + NT fragment reads of the next
+  // K-step go out one per two MFMAs of the current one (a burst of reads in
+  // front of a burst of MFMAs leaves the LDS pipe and the matrix pipe taking
+  // turns; both waves of a SIMD reach their bursts together after a barrier)
+  auto interleave = [&]() {
+    if (!kSwpInterleave) return;
+#pragma unroll
+    for (int i = 0; i < MT + NT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, (MT * NT) / (MT + NT), 0);
+    }
+  };
+
+  // ---- prologue: window of pass 0, weight stages 0..2, first fragments --------
+  issue_a_range(0, 0, KPW);
+  issue_b(0);
+  if (pa.total_stages > 1) issue_b(1);
+  if (pa.total_stages > 2) issue_b(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 af0[MT], bf0[NT], af1[MT], bf1[NT];
+  read_frags(af0, bf0, 0, 0, 0, 0);
+  landed(af0);
+  landed(bf0);
+
+  int gs = 0;
+  int na_prev = 0;  // window pieces this wave issued in the previous stage
+  for (int p = 0; p < pa.npass; ++p) {
+    const int nst_p = p >= full_passes ? 4 : pa.nst;
+    for (int s = 0; s < nst_p; ++s, ++gs) {
+      // ---- first half: K-step 1 is read while K-step 0 multiplies -----------
+      read_frags(af1, bf1, p, s, gs, 1);
+      if (!kSwpInterleave) __builtin_amdgcn_sched_barrier(0);
+      mfma_step(af0, bf0);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      landed(af1);
+      landed(bf1);
+      // ---- stage boundary ----------------------------------------------------
+      // weight stage gs + 1 (issued two stages ago) and every window piece but
+      // those of the previous stage have landed once all but this wave's newest
+      // (stage gs + 2, previous stage's window pieces) DMAs are done; the
+      // barrier publishes them and frees slot gs / the other window buffer
+      {
+        const int nb = gs + 2 < pa.total_stages ? NBW : 0;
+        if (na_prev == 0) {
+          if (nb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (na_prev == 1) {
+          if (nb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW + 1) : "memory");
+          else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        } else {
+          if (nb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW + 2) : "memory");
+          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      // ---- second half: K-step 0 of the next stage is read while K-step 1
+      // multiplies
+      if (gs + 1 < pa.total_stages) {
+        const bool last_of_pass = s + 1 == nst_p;
+        read_frags(af0, bf0, last_of_pass ? p + 1 : p, last_of_pass ? 0 : s + 1,
+                   gs + 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // (the DMA issue sits behind the reads: in front of them the LDS pipe and
+      // the matrix pipe both idle while the wave builds addresses)
+      if (gs + 3 < pa.total_stages) issue_b(gs + 3);
+      // window of the next pass: issued in stages 0 .. nst - 3 of this pass, so
+      // the wait of stage nst - 1 (which leaves only the previous stage's
+      // pieces in flight) retires all of them before the first read
+      na_prev = 0;
+      if (p + 1 < pa.npass && s <= nst_p - 3)
+        na_prev = issue_a_range(p + 1, s * pa.apw, (s + 1) * pa.apw);
+      mfma_step(af1, bf1);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      landed(af0);
+      landed(bf0);
+    }
+  }
+
+  // ---- epilogue: accumulators -> LDS -> whole-line row-contiguous stores ------
+  // (the non-LayerNorm epilogue of swconv_kernel; 16x16 accumulators)
+  __syncthreads();
+  float* scr = reinterpret_cast<float*>(smem) + wave * (16 * kSwpScrPitch);
+  const int erow = lane >> 3;
+  const int cg8 = lane & 7;
+  const bool of32 = a.out_f32;
+  const int colA = of32 ? cg8 * 4 : cg8 * 8;
+  const int colB = of32 ? colA + 32 : colA + 4;
+  const int nA = n0 + wn * 64 + colA;
+  const int nB = n0 + wn * 64 + colB;
+  float ssq = 0.f;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bv[e] = (a.bias && nA + e < a.N) ? a.bias[nA + e] : 0.f;
+    bv[4 + e] = (a.bias && nB + e < a.N) ? a.bias[nB + e] : 0.f;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        scr[(4 * g + r) * kSwpScrPitch + nt * 16 + rM] = acc[mt][nt][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = pass * 8 + erow;
+      const int m = m0 + (wm * MT + mt) * 16 + row;
+      if (m < a.M && nA < a.Cy) {
+        const int b = m / a.Lu;
+        const int u = m - b * a.Lu;
+        int t = a.y_stride * u + y_off;
+        bool to_side = false;
+        if (a.out_shifts) {
+          const int s = a.out_shifts[b / a.out_seg];
+          if (s > 0) {
+            to_side = t >= a.Ly - s;
+            t = to_side ? t - (a.Ly - s) : t + s;
+          } else {
+            to_side = t < -s;
+            t = to_side ? t : t + s;
+          }
+        }
+        const long long rowoff =
+            ((long long)b * (to_side ? a.side_rows : a.Ly) + t) * a.Cy;
+        const f32x4 v0 =
+            *reinterpret_cast<const f32x4*>(scr + row * kSwpScrPitch + colA);
+        const f32x4 v1 =
+            *reinterpret_cast<const f32x4*>(scr + row * kSwpScrPitch + colB);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const bool okB = nB < a.Cy;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        if (a.epilogue == CG_EPI_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], a.alpha * v[e]);
+        } else if (a.epilogue == CG_EPI_MASK && !to_side) {
+          if (a.out_shifts) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+          }
+          const uint2 ha = *reinterpret_cast<const uint2*>(a.mask + rowoff + nA);
+          const uint2 hb = okB ? *reinterpret_cast<const uint2*>(a.mask + rowoff + nB)
+                               : make_uint2(0u, 0u);
+          const uint32_t hw[4] = {ha.x, ha.y, hb.x, hb.y};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint16_t hv = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
+            v[e] *= (bf2f(hv) > 0.f) ? 1.f : a.alpha;
+          }
+        } else if (a.epilogue == CG_EPI_SIGMOID) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (nA + e >= a.N) v[e] = 0.f;
+          if (nB + e >= a.N) v[4 + e] = 0.f;
+        }
+        if (a.rowsumsq) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
+        }
+        if (a.out_f32) {
+          float* dst = reinterpret_cast<float*>(a.y) + rowoff;
+          *reinterpret_cast<f32x4*>(dst + nA) = f32x4{v[0], v[1], v[2], v[3]};
+          if (okB)
+            *reinterpret_cast<f32x4*>(dst + nB) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          uint16_t* dst =
+              (to_side ? a.side : reinterpret_cast<uint16_t*>(a.y)) + rowoff + nA;
+          *reinterpret_cast<uint4*>(dst) =
+              make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
+                         pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (a.rowsumsq) {
+    // the whole tile belongs to one sample (nseg == 1, checked on the host): one
+    // f32 atomic per workgroup
+    ssq = wave_sum(ssq);
+    float* wsum = reinterpret_cast<float*>(smem) + NW * 16 * kSwpScrPitch;
+    if (lane == 0) wsum[wave] = ssq;
+    __syncthreads();
+    if (tid == 0 && m0 < a.M) {
+      float t = 0.f;
+      for (int w = 0; w < NW; ++w) t += wsum[w];
+      atomicAdd(a.rowsumsq + b0, t);
+    }
+  }
+}
+
+template <int R, int WM, int WN, int MT>
+int launch_swp(const SwpArgs& pa, dim3 grid, size_t lds, bool dry, hipStream_t s) {
+  if (dry) return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&swconv_swp_kernel<R, WM, WN, MT>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  CG_LAUNCH_PROF(CG_FAMILY_SWCONV, (swconv_swp_kernel<R, WM, WN, MT>), grid,
+                 dim3(WM * WN * 64), lds, s, pa);
+  CG_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
+                      int ksplit, bool dry, hipStream_t stream) {
+  // uniform 32-channel K walk, one tap per K-step; no LayerNorm epilogue, no
+  // split-K (the tile kernels keep those)
+  if (a.CK != 32 || a.taps % stride || ksplit > 1 ||
+      a.epilogue == CG_EPI_LN_LRELU)
+    return CG_EINVAL;
+  if (stride == 2 && !a.pmajor) return CG_EINVAL;
+  const int nw = wm * wn, tn = wn * 64;
+  static const void* zero_page = nullptr;
+  if (!zero_page &&
+      hipGetSymbolAddress(const_cast<void**>(&zero_page), HIP_SYMBOL(g_zero_page)) !=
+          hipSuccess)
+    return CG_EINVAL;
+  SwpArgs pa;
+  pa.c = a;
+  pa.zero = reinterpret_cast<const unsigned char*>(zero_page);
+  pa.tpp = a.taps / stride;
+  // whole 64-deep stages per pass, and stages 0 .. nst - 3 to issue the next
+  // window in
+  if (pa.tpp % 2 || pa.tpp / 2 < 3) return CG_EINVAL;
+  pa.nst = pa.tpp / 2;
+  pa.WRs = a.S + pa.tpp - 1;
+  pa.wrows = a.nseg * pa.WRs;
+  pa.npa = (pa.wrows * 64 + 1023) / 1024;
+  pa.abytes = pa.npa * 1024;
+  // a wave's piece slots k = 0 .. ceil(npa / nw) - 1 are spread over the nst - 2
+  // issuing stages, apw per stage (the counted waits cover 0..2 pieces)
+  const int kpw = (pa.npa + nw - 1) / nw;
+  pa.apw = (kpw + (pa.nst - 2) - 1) / (pa.nst - 2);
+  if (pa.apw > 2 || a.nseg > 8 || a.S < 16 * mt) return CG_EINVAL;
+  const int narrow = a.narrow ? 1 : 0;
+  if (narrow && (stride != 2 || a.nchunks < 2)) return CG_EINVAL;
+  pa.npass = (a.nchunks - narrow) * stride + narrow;
+  pa.total_stages = (a.nchunks - narrow) * stride * pa.nst + narrow * 4;
+  pa.npad_rows = (a.N + 127) / 128 * 128;
+  pa.inv_WRs = 1.0f / (float)pa.WRs;
+  size_t lds = (size_t)2 * pa.abytes + (size_t)kSwpRing * tn * 64 * 2 + 128;
+  const size_t epi = (size_t)nw * 16 * kSwpScrPitch * 4 + 64;
+  if (lds < epi) lds = epi;
+  if (lds > 160 * 1024) return CG_EINVAL;
+  dim3 grid((unsigned)(((a.gm + 7) / 8) * 8 * a.gn * a.gp));
+#define CG_SWP(RR, WM, WN, MM)                                  \
+  if (stride == RR && wm == WM && wn == WN && mt == MM)         \
+    return launch_swp<RR, WM, WN, MM>(pa, grid, lds, dry, stream);
+#define CG_SWP_R(WM, WN, MM) CG_SWP(1, WM, WN, MM) CG_SWP(2, WM, WN, MM)
+  CG_SWP_R(8, 1, 4)   // 512 x 64, 8 waves
+  CG_SWP_R(4, 1, 4)   // 256 x 64, 4 waves
+  CG_SWP_R(4, 2, 4)   // 256 x 128, 8 waves
+  CG_SWP_R(2, 2, 4)   // 128 x 128, 4 waves
+  CG_SWP_R(2, 4, 4)   // 128 x 256, 8 waves
+#undef CG_SWP_R
+#undef CG_SWP
+  return CG_EINVAL;
+}

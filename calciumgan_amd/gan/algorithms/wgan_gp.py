@@ -41,6 +41,11 @@ _FORCE_SPLIT = os.environ.get('CALCIUMGAN_SPLIT_SEGMENTS', '0') == '1'
 # of a step (CALCIUMGAN_BATCH_G=0: one pass per update, as under data
 # parallelism, where each pass hides the previous update's all-reduce)
 _BATCH_G = os.environ.get('CALCIUMGAN_BATCH_G', '1') != '0'
+_METRIC_KEYS = ('signals_metrics/min', 'signals_metrics/max',
+                'signals_metrics/mean', 'signals_metrics/std')
+# pinned staging slots for the host-drawn inputs of a graph replay: the host may
+# run this many steps ahead of the GPU before it waits for a slot's copy
+_STAGING_SLOTS = 4
 
 
 @register('wgan-gp')
@@ -72,7 +77,10 @@ class WGAN_GP(GAN):
           gp=torch.zeros(max(self.n_critic, 1), dtype=torch.float32, device=dev),
           loss=torch.zeros(max(self.n_critic, 1), 2, dtype=torch.float32,
                            device=dev),
-          gen_loss=torch.zeros(1, dtype=torch.float32, device=dev))
+          gen_loss=torch.zeros(1, dtype=torch.float32, device=dev),
+          # the step's outputs [gen_loss, dis_loss, gp, metrics x 4], written
+          # by the last launches of train(); train() hands out a COPY
+          out=torch.zeros(7, dtype=torch.float32, device=dev))
       st['critic'].coef.copy_(torch.tensor([-1.0 / B, 1.0 / B, 1.0]))
       st['critic'].bias_coef.copy_(torch.tensor([-1.0 / B, 1.0 / B, 0.0]))
       st['critic'].build_jvp(2)
@@ -292,10 +300,12 @@ class WGAN_GP(GAN):
 
     def last_seg():
       metrics = self._gen_apply(real, lr(n), metrics=box.pop('metrics'))
-      dis_loss = st['loss'][:n, 0].mean()
-      gradient_penalty = st['gp'][:n].mean()
-      out['value'] = (st['gen_loss'][0].clone(), dis_loss, gradient_penalty,
-                      metrics)
+      o = st['out']
+      o[0:1].copy_(st['gen_loss'])
+      o[1:2].copy_(st['loss'][:n, 0].mean(0, keepdim=True))
+      o[2:3].copy_(st['gp'][:n].mean(0, keepdim=True))
+      o[3:7].copy_(torch.stack([metrics[k] for k in _METRIC_KEYS]))
+      out['value'] = o
 
     segs = []
     for i in range(n):
@@ -340,25 +350,42 @@ class WGAN_GP(GAN):
     if pending is not None:
       pending.wait()
 
+  def _outputs(self, o):
+    """(gen_loss, dis_loss, gradient_penalty, metrics) as views of a fresh
+    COPY of the step's output buffer: the buffer itself is rewritten by the next
+    train() -- in place, when the step replays as a graph -- so callers may keep
+    the returned tensors across steps without a host sync (main.py averages
+    them at the end of the epoch).  Data parallel: averaged over the ranks, one
+    7-float all-reduce per step."""
+    o = self._sync.mean_scalars(o.clone())
+    return (o[0], o[1], o[2],
+            {k: o[3 + i] for i, k in enumerate(_METRIC_KEYS)})
+
   def _train_body(self, real, rand=None):
     segs, out = self._segments(real, rand)
     self._run_segments(segs, lambda fn: fn())
-    return out['value']
+    return self._outputs(out['value'])
 
   def _capture(self, real, st):
     """Capture one train() as hipGraphs, one per segment (RCCL all-reduces stay
-    eager between replays, overlapped with the wait=False segments).  Host-drawn inputs of a replay (phase shifts, Adam
-    step sizes) travel through pinned staging buffers that the first graph
-    copies to the device; z / alpha come from the graph-registered device
-    generator."""
+    eager between replays, overlapped with the wait=False segments).
+    Host-drawn inputs of a replay (phase shifts, Adam step sizes) are copied
+    to fixed device buffers EAGERLY ahead of the replay, from a ring of pinned
+    staging slots (_stage_host_inputs); z / alpha come from the
+    graph-registered device generator."""
     dev = self.device
     n = self.n_critic
     g = dict(
         real=torch.empty_like(real),
-        shifts_host=torch.zeros(n * 12 + 4, dtype=torch.int32).pin_memory(),
-        shifts_dev=torch.zeros(n * 12 + 4, dtype=torch.int32, device=dev),
-        lr_host=torch.zeros(n + 1, dtype=torch.float32).pin_memory(),
-        lr_dev=torch.zeros(n + 1, dtype=torch.float32, device=dev))
+        # one staging word array per slot: [shifts int32 x (12 n + 4) |
+        # lr_t f32 x (n + 1)] (the f32 part travels as its bit pattern)
+        stage_host=[torch.zeros(n * 13 + 5, dtype=torch.int32).pin_memory()
+                    for _ in range(_STAGING_SLOTS)],
+        stage_event=[None] * _STAGING_SLOTS,
+        stage_next=0,
+        stage_dev=torch.zeros(n * 13 + 5, dtype=torch.int32, device=dev))
+    g['shifts_dev'] = g['stage_dev'][:n * 12 + 4]
+    g['lr_dev'] = g['stage_dev'][n * 12 + 4:].view(torch.float32)
     g['real'].copy_(real)
     rand = dict(
         critic=[dict(shifts_dev=g['shifts_dev'][12 * i:12 * i + 12].view(4, 3))
@@ -377,9 +404,6 @@ class WGAN_GP(GAN):
         # while this thread captures
         with torch.cuda.graph(graph, pool=pool,
                               capture_error_mode='thread_local'):
-          if k == 0:
-            g['shifts_dev'].copy_(g['shifts_host'], non_blocking=True)
-            g['lr_dev'].copy_(g['lr_host'], non_blocking=True)
           fn()
         pool = graph.pool()
         graphs.append((graph.replay, grad, wait))
@@ -405,27 +429,48 @@ class WGAN_GP(GAN):
         torch.cuda.synchronize()
         return self._train_body(real)
     n = self.n_critic
-    if g['real'].data_ptr() != real.data_ptr():
-      g['real'].copy_(real)
-    sh = g['shifts_host']
-    for i in range(n):
-      sh[12 * i:12 * i + 12] = self._streams.shifts(3).reshape(-1)
-    sh[12 * n:] = self._streams.shifts(1).reshape(-1)
-    for i in range(n):
-      g['lr_host'][i] = self.dis_optimizer.lr_t(self.dis_optimizer.iterations +
-                                                i + 1)
-    g['lr_host'][n] = self.gen_optimizer.lr_t(self.gen_optimizer.iterations + 1)
+    # the graphs read their batch from a private buffer (107 MB at cfg2,
+    # ~35 us): the caller's tensor is a fresh gather every step
+    g['real'].copy_(real)
+    self._stage_host_inputs(g)
     self._run_segments(g['graphs'], lambda replay: replay())
     self.dis_optimizer.iterations += n
     self.gen_optimizer.iterations += 1
-    return g['out']
+    return self._outputs(g['out'])
+
+  def _stage_host_inputs(self, g):
+    """Phase shifts and Adam step sizes of the coming replay -> device.  The
+    host writes them into the next pinned slot of a ring and enqueues the copy
+    on the launch stream (ordered after the previous replay, which still reads
+    the device buffer); an event per slot keeps the host from rewriting a slot
+    whose copy has not executed yet -- train() never syncs, so the host may
+    run several steps ahead of the GPU."""
+    n = self.n_critic
+    k = g['stage_next']
+    g['stage_next'] = (k + 1) % _STAGING_SLOTS
+    if g['stage_event'][k] is not None:
+      g['stage_event'][k].synchronize()
+    host = g['stage_host'][k]
+    for i in range(n):
+      host[12 * i:12 * i + 12] = self._streams.shifts(3).reshape(-1)
+    host[12 * n:12 * n + 4] = self._streams.shifts(1).reshape(-1)
+    lr = host[12 * n + 4:].view(torch.float32)
+    for i in range(n):
+      lr[i] = self.dis_optimizer.lr_t(self.dis_optimizer.iterations + i + 1)
+    lr[n] = self.gen_optimizer.lr_t(self.gen_optimizer.iterations + 1)
+    g['stage_dev'].copy_(host, non_blocking=True)
+    ev = g['stage_event'][k] = torch.cuda.Event()
+    ev.record()
 
   def train(self, inputs, rand=None):
     """wgan_gp.py:82-95: n_critic critic updates on the SAME batch, then one
     generator update.  Returns (gen_loss, dis_loss, gradient_penalty, metrics)
-    as 0-d device tensors (no host sync inside).  `rand` optionally injects the
-    random draws (same structure as oracle.draw_randomness) for parity tests.
-    After two eager calls per batch size the step replays as hipGraphs."""
+    as 0-d device tensors (no host sync inside; each call returns views of its
+    own small buffer, so they stay valid across later steps; under data
+    parallelism they are the means over all ranks).  `rand` optionally injects
+    the random draws (same structure as oracle.draw_randomness) for parity
+    tests.  After two eager calls per batch size the step replays as
+    hipGraphs."""
     real = self._to_device(inputs)
     if rand is None and self._use_graph:
       st = self._get_state(real.shape[0])
@@ -455,6 +500,8 @@ class WGAN_GP(GAN):
     fake = self._critic_forward(st, real, z, alpha, shifts, 0)
     C = self.generator.net.C
     metrics = self.metrics(real, fake, fake_pitch=self.generator.net.Cf)
-    loss = st['loss'][0].clone()
-    return (fake[:, :, :C].clone(), loss[1], loss[0], st['gp'][0].clone(),
-            metrics)
+    loss = st['loss'][0]
+    gen_loss, dis_loss, gp, metrics = self._outputs(
+        torch.stack([loss[1], loss[0], st['gp'][0]] +
+                    [metrics[k] for k in _METRIC_KEYS]))
+    return fake[:, :, :C].clone(), gen_loss, dis_loss, gp, metrics

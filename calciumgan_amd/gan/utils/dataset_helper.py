@@ -73,7 +73,8 @@ def get_dataset_info(hparams):
     hparams.signals_max = float(info['signals_max'])
   if hparams.save_generated:
     hparams.generated_dir = os.path.join(hparams.output_dir, 'generated')
-    os.makedirs(hparams.generated_dir, exist_ok=True)
+    if getattr(hparams, 'rank', 0) == 0:
+      os.makedirs(hparams.generated_dir, exist_ok=True)
     hparams.validation_cache = os.path.join(hparams.generated_dir,
                                             'validation.h5')
 
@@ -92,12 +93,60 @@ def cache_validation_set(hparams, validation):
   })
 
 
+SURROGATE_TRAIN_SIZE = 8192  # dataset_helper.py:76
+
+
+def get_surrogate_dataset(hparams):
+  """dataset_helper.py:54-110: <input_dir>/training.pkl holds
+  {'signals': (trials, neurons, time), 'spikes': ...}; signals become
+  (trials, time, neurons), are min-max normalised over the WHOLE array (the
+  bounds land in hparams.signals_min / signals_max), and the first 8192
+  trials train, the rest validate."""
+  filename = os.path.join(hparams.input_dir, 'training.pkl')
+  if not os.path.exists(filename):
+    print('training dataset {} not found'.format(filename))
+    exit()
+  with open(filename, 'rb') as file:
+    data = pickle.load(file)
+  signals = np.ascontiguousarray(
+      np.transpose(np.asarray(data['signals'], dtype=np.float32), (0, 2, 1)))
+  spikes = np.asarray(data['spikes'])
+  hparams.signals_min = float(signals.min())
+  hparams.signals_max = float(signals.max())
+  signals = ((signals - hparams.signals_min) /
+             (hparams.signals_max - hparams.signals_min)).astype(np.float32)
+  n = SURROGATE_TRAIN_SIZE
+  hparams.train_size = len(signals[:n])
+  hparams.validation_size = len(signals[n:])
+  hparams.signal_shape = tuple(signals.shape[1:])
+  hparams.spike_shape = tuple(spikes.shape[1:])
+  hparams.sequence_length = signals.shape[1]
+  hparams.num_neurons = hparams.num_channels = signals.shape[-1]
+  hparams.normalize, hparams.fft, hparams.conv2d = True, False, False
+  if hparams.save_generated:
+    hparams.generated_dir = os.path.join(hparams.output_dir, 'generated')
+    if getattr(hparams, 'rank', 0) == 0:
+      os.makedirs(hparams.generated_dir, exist_ok=True)
+    hparams.validation_cache = os.path.join(hparams.generated_dir,
+                                            'validation.h5')
+  return (ArrayDataset(signals[:n], spikes[:n], hparams.batch_size,
+                       shuffle=True),
+          ArrayDataset(signals[n:], spikes[n:], hparams.batch_size,
+                       shuffle=False))
+
+
 def get_dataset(hparams, summary=None):
   """dataset_helper.py:185-206."""
   hparams.noise_shape = (hparams.noise_dim,)
   if not os.path.exists(hparams.input_dir):
     print('input directory {} cannot be found'.format(hparams.input_dir))
     exit()
+  if getattr(hparams, 'surrogate_ds', False):
+    train_ds, validation_ds = get_surrogate_dataset(hparams)
+    hparams.train_steps = ceil(hparams.train_size / hparams.batch_size)
+    hparams.validation_steps = ceil(hparams.validation_size /
+                                    hparams.batch_size)
+    return train_ds, validation_ds
   get_dataset_info(hparams)
   if os.path.exists(os.path.join(hparams.input_dir, 'train.npy')):
     with open(os.path.join(hparams.input_dir, 'train.npy'), 'rb') as f:
@@ -114,8 +163,8 @@ def get_dataset(hparams, summary=None):
         os.path.join(hparams.input_dir, mode + '-*.record'),
         hparams.signal_shape, hparams.spike_shape)
                        for mode in ('train', 'validation')))
-  if hparams.save_generated:
-    cache_validation_set(hparams, validation)
+  if hparams.save_generated and getattr(hparams, 'rank', 0) == 0:
+    cache_validation_set(hparams, validation)  # one writer under torchrun
   train_ds = ArrayDataset(train['signals'], train['spikes'], hparams.batch_size,
                           shuffle=True)
   validation_ds = ArrayDataset(validation['signals'], validation['spikes'],

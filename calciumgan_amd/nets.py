@@ -284,6 +284,11 @@ _AUTOTUNE = __import__('os').environ.get('CALCIUMGAN_AUTOTUNE', '1') != '0'
 # file, so later processes (profiler passes, the other ranks' restarts) launch
 # exactly the tuned configuration without re-timing candidates.
 _TILE_CACHE_FILE = __import__('os').environ.get('CALCIUMGAN_TILE_CACHE')
+# CALCIUMGAN_TUNE_LOG=<file.jsonl>: every tuned geometry with all candidates'
+# times (per-geometry tables under profiles/ come from this)
+_TUNE_LOG = __import__('os').environ.get('CALCIUMGAN_TUNE_LOG')
+# CALCIUMGAN_SWP_TILES=0: the software-pipelined tiles are not offered to the tuner
+_SWP_TILES = __import__('os').environ.get('CALCIUMGAN_SWP_TILES', '1') != '0'
 
 
 def _load_tile_cache():
@@ -297,6 +302,9 @@ def _load_tile_cache():
 
 def _save_tile_cache():
   import json
+  from . import parallel
+  if parallel.env_rank() != 0:  # one writer under torchrun
+    return
   if _TILE_CACHE_FILE and _TILE_CACHE:
     with open(_TILE_CACHE_FILE, 'w') as f:
       json.dump({','.join(str(t) for t in k): list(v)
@@ -310,10 +318,26 @@ __import__('atexit').register(_save_tile_cache)
 def _autotune_tile(d):
   if not torch.cuda.is_available():
     return
+  # everything that decides which candidates are VALID is part of the key (a
+  # choice tuned for an unconstrained launch must not reach a constrained one)
   key = (d.stride, d.taps, d.nB, d.Lx, d.Cx, d.Lu, d.N, d.CK, d.nphase,
-         d.epilogue, d.out_f32, d.w_narrow_last)
+         d.epilogue, d.out_f32, d.w_narrow_last, int(bool(d.rowsumsq)),
+         int(bool(d.out_shifts)), int(bool(d.split_ws)))
+  from . import parallel
+  multi = parallel.world_size() > 1
   best = _TILE_CACHE.get(key)
+  if multi:
+    # every rank builds the same descriptors in the same order: rank 0 tunes
+    # (or reads its cache) and all ranks launch ITS choice -- identical kernels
+    # and reduction orders on every rank
+    if parallel.rank() != 0:
+      best = parallel.broadcast_object(None)
+      if best is not None:
+        _TILE_CACHE[key] = best
+      return _apply_tile_choice(d, best)
   if best is None and not _AUTOTUNE:
+    if multi:
+      parallel.broadcast_object(None)
     return
   if best is None:
     lib = _lib.load()
@@ -334,6 +358,19 @@ def _autotune_tile(d):
                               mf) <= geo.LDS_BYTES:
         cands.append(small)
     cands = [(small, ks, 0, 1) for small in cands for ks in (2, 4)]
+    swp = []
+    if (_SWP_TILES and d.CK == 32 and d.epilogue != _lib.EPI_LN_LRELU and
+        d.taps % d.stride == 0 and (d.taps // d.stride) % 2 == 0 and
+        d.taps // d.stride >= 6 and (d.stride == 1 or d.w_parity_major)):
+      # software-pipelined tiles (two waves per SIMD, swconv_swp.hip)
+      for small, (tm, tn) in _lib.SWP_TILES.items():
+        ok = (d.Lu % tm == 0) if d.Lu >= tm else (tm % d.Lu == 0)
+        if d.rowsumsq and d.Lu < tm:
+          ok = False
+        if tn > 64 and d.N <= (tn // 2 if tn > 128 else 64):
+          ok = False
+        if ok:
+          swp.append((small, 2, 0, 1))
     if d.stride == 2 and d.w_parity_major:
       # split-parity staging: half the LDS window, twice the staging phases
       cands += [(small, ks, 1, 1) for small, ks, _, _ in list(cands)
@@ -344,6 +381,7 @@ def _autotune_tile(d):
       nch = d.Cx // d.CK
       cands += [(small, ks, sp, z) for small, ks, sp, _ in list(cands)
                 for z in (2, 4) if nch % z == 0]
+    cands += swp
     times = {}
     y_saved = d.y
     scratch = None
@@ -372,12 +410,34 @@ def _autotune_tile(d):
     d.split_parity = 0
     d.ksplit = 0
     del scratch
-    if not times:
-      return
-    best = min(times, key=times.get)
-    _TILE_CACHE[key] = best
+    if times:
+      best = min(times, key=times.get)
+      _TILE_CACHE[key] = best
+      if _TUNE_LOG:
+        import json
+        with open(_TUNE_LOG, 'a') as f:
+          f.write(json.dumps({
+              'key': list(key),
+              'times_us': {','.join(map(str, c)): round(t / 3 * 1e3, 2)
+                           for c, t in sorted(times.items(),
+                                              key=lambda kv: kv[1])}}) + '\n')
+  if multi:
+    parallel.broadcast_object(best)
+  _apply_tile_choice(d, best)
+
+
+def _apply_tile_choice(d, best):
+  """Set a tuned (tile, stage depth, split-parity, split-K) choice on a
+  descriptor after checking that the library accepts it for THIS launch (a
+  file-loaded table may come from another build); the static default stays
+  otherwise."""
+  if best is None:
+    return
+  saved = (d.tile, d.stage_ksteps, d.split_parity, d.ksplit)
   d.tile, d.stage_ksteps, d.split_parity = best[:3]
   d.ksplit = best[3] if len(best) > 3 and d.split_ws else 0
+  if _lib.load().cg_swconv_check(ctypes.byref(d)) != 0:
+    d.tile, d.stage_ksteps, d.split_parity, d.ksplit = saved
 
 
 # K'-split partial sums of cg_wgrad: plain stores + a reducing launch instead of

@@ -103,3 +103,49 @@ class RandomStreams(object):
     """int32 (4, nseg): U{-m..m} per layer per discriminator call."""
     return torch.randint(-self.m, self.m + 1, (4, nseg), generator=self.shared,
                          dtype=torch.int32)
+
+
+def barrier():
+  if dist.is_initialized():
+    dist.barrier()
+
+
+def shard_batch(batch, r=None, world=None):
+  """Rank r's samples of a global batch: r::world of the largest prefix that
+  divides evenly, so every rank holds the SAME number of samples and the
+  (1/world) * sum of local-mean gradients is the global mean.  Up to world - 1
+  samples of a ragged last batch are dropped; returns None when the batch is
+  smaller than the world (every rank then skips it -- all ranks see the same
+  batch, so the decision is consistent and no collective is left hanging)."""
+  world = world_size() if world is None else world
+  r = rank() if r is None else r
+  if world <= 1:
+    return batch
+  n = (len(batch) // world) * world
+  if n == 0:
+    return None
+  return batch[:n][r::world]
+
+
+def gather_batch(local, dst=0):
+  """Inverse of shard_batch for equal shards: the global batch (sample order
+  restored) on rank dst, None elsewhere.  Used for the generated samples of a
+  validation pass (files are written by rank 0 only)."""
+  if not dist.is_initialized() or dist.get_world_size() == 1:
+    return local
+  world = dist.get_world_size()
+  parts = [torch.empty_like(local) for _ in range(world)]
+  dist.all_gather(parts, local.contiguous())
+  if dist.get_rank() != dst:
+    return None
+  out = torch.stack(parts, dim=1)  # (n_local, world, ...): sample i*world + r
+  return out.reshape((-1,) + tuple(local.shape[1:]))
+
+
+def broadcast_object(obj, src=0):
+  """A small picklable object from rank src to every rank (tile choices)."""
+  if not dist.is_initialized() or dist.get_world_size() == 1:
+    return obj
+  box = [obj]
+  dist.broadcast_object_list(box, src=src)
+  return box[0]

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 8
+#define CG_ABI_VERSION 9
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -49,7 +49,18 @@ extern "C" {
 #define CG_TILE_128x128_M32 6
 #define CG_TILE_256x128 7
 #define CG_TILE_128x128 8
-#define CG_NUM_TILES 9
+/* Software-pipelined tiles (swconv_swp.hip): two waves per SIMD (one 8-wave
+ * workgroup or two 4-wave workgroups per CU), fragments double-buffered in
+ * registers at K-step granularity, the source window and the weight ring both
+ * filled by LDS-DMA.  v_mfma_f32_16x16x32, CK == 32, at least six taps per
+ * source-row parity; no LayerNorm epilogue, no split-K.  Same results as the
+ * tiles above. */
+#define CG_TILE_SWP_512x64 9
+#define CG_TILE_SWP_256x64 10
+#define CG_TILE_SWP_256x128 11
+#define CG_TILE_SWP_128x128 12
+#define CG_TILE_SWP_128x256 13
+#define CG_NUM_TILES 14
 
 int cg_abi_version(void);
 /* sizeof() of the descriptor structs as this library was compiled
@@ -156,6 +167,10 @@ typedef struct cg_conv_desc {
 } cg_conv_desc;
 
 int cg_swconv(const cg_conv_desc* d, void* stream);
+/* Validate a descriptor exactly as cg_swconv would (geometry, tile, LDS budget,
+ * epilogue / split-K constraints) without launching anything: 0 or CG_EINVAL.
+ * The host uses it before adopting a tile choice from a saved table. */
+int cg_swconv_check(const cg_conv_desc* d);
 
 /* Streaming form of the 1-tap case with f32 output (the generator's last
  * layers.Dense + sigmoid, calciumgan.py:96-101; HBM-bound):

@@ -30,6 +30,8 @@ def train(hparams, train_ds, gan, summary, epoch):
   start = time()
   for signal, _ in train_ds:
     signal = _shard(hparams, signal)
+    if signal is None:  # ragged last batch smaller than the world size
+      continue
     gen_loss, dis_loss, gradient_penalty, metrics = gan.train(signal)
     gen_losses.append(gen_loss)
     dis_losses.append(dis_loss)
@@ -51,6 +53,7 @@ def train(hparams, train_ds, gan, summary, epoch):
 
 def validate(hparams, validation_ds, gan, summary, epoch):
   """main.py:78-122."""
+  from calciumgan_amd import parallel
   from calciumgan_amd.gan.utils import utils
   gen_losses, dis_losses, gradient_penalties, results = [], [], [], {}
   save_generated = (hparams.save_generated == 'all' and
@@ -60,6 +63,8 @@ def validate(hparams, validation_ds, gan, summary, epoch):
   start = time()
   for signal, _ in validation_ds:
     signal = _shard(hparams, signal)
+    if signal is None:
+      continue
     fake, gen_loss, dis_loss, gradient_penalty, metrics = gan.validate(signal)
     gen_losses.append(float(gen_loss))
     dis_losses.append(float(dis_loss))
@@ -67,8 +72,11 @@ def validate(hparams, validation_ds, gan, summary, epoch):
       gradient_penalties.append(float(gradient_penalty))
     for key, item in metrics.items():
       results.setdefault(key, []).append(float(item))
-    if save_generated and hparams.rank == 0:
-      utils.save_fake_signals(hparams, epoch, signals=fake)
+    if save_generated:
+      # every rank generated its shard: the whole batch goes to rank 0's file
+      fake = parallel.gather_batch(fake)
+      if hparams.rank == 0:
+        utils.save_fake_signals(hparams, epoch, signals=fake)
   gen_loss, dis_loss = float(np.mean(gen_losses)), float(np.mean(dis_losses))
   results = {key: float(np.mean(item)) for key, item in results.items()}
   end = time()
@@ -107,16 +115,24 @@ def test(validation_ds, gan, hparams):
   """main.py:168-181."""
   results = {}
   for signal, _ in validation_ds:
-    _, _, _, _, metrics = gan.validate(_shard(hparams, signal))
+    signal = _shard(hparams, signal)
+    if signal is None:
+      continue
+    _, _, _, _, metrics = gan.validate(signal)
     for key, item in metrics.items():
       results.setdefault(key, []).append(float(item))
   return {key: float(np.mean(item)) for key, item in results.items()}
 
 
 def _shard(hparams, batch):
-  """Data parallel: rank r takes samples r::world of every batch."""
+  """Data parallel: rank r takes samples r::world of every batch, equal
+  shares on every rank (parallel.shard_batch: up to world - 1 samples of a
+  ragged last batch are dropped, None = skip the batch on every rank).  The
+  losses / metrics train() and validate() return are already means over the
+  ranks."""
   if hparams.world_size > 1:
-    batch = batch[hparams.rank::hparams.world_size]
+    from calciumgan_amd import parallel
+    return parallel.shard_batch(batch, hparams.rank, hparams.world_size)
   return batch
 
 
@@ -134,14 +150,17 @@ def main(hparams, return_metrics=False):
   parallel.init_process_group()
   hparams.rank, hparams.world_size = parallel.rank(), parallel.world_size()
 
-  if hparams.clear_output_dir and os.path.exists(
-      hparams.output_dir) and hparams.rank == 0:
-    rmtree(hparams.output_dir)
-  os.makedirs(hparams.output_dir, exist_ok=True)
+  if hparams.rank == 0:
+    if hparams.clear_output_dir and os.path.exists(hparams.output_dir):
+      rmtree(hparams.output_dir)
+    os.makedirs(hparams.output_dir, exist_ok=True)
+  # the other ranks touch the output directory only after rank 0 has set it up
+  parallel.barrier()
 
   hparams.focus_neurons = [87, 58, 90, 39, 7, 60, 14, 5, 13]
   summary = Summary(hparams) if hparams.rank == 0 else None
   train_ds, validation_ds = get_dataset(hparams, summary)
+  parallel.barrier()  # rank 0 wrote generated/validation.h5
   generator, discriminator = get_models(hparams, summary)
   if hparams.rank == 0:
     utils.save_hparams(hparams)

@@ -66,11 +66,13 @@ def test_packed_elems_host_formula():
 def test_tile_table_matches_library():
   lib = _lib.load()
   import ctypes
-  for tile, (rows, cols, _) in _lib.TILES.items():
+  tiles = sorted(list(_lib.TILES) + list(_lib.SWP_TILES))
+  assert tiles == list(range(len(tiles)))
+  for tile in tiles:
     r, c = ctypes.c_int(), ctypes.c_int()
     assert lib.cg_tile_shape(tile, ctypes.byref(r), ctypes.byref(c)) == 0
-    assert (r.value, c.value) == (rows, cols)
-  assert lib.cg_tile_shape(len(_lib.TILES), None, None) == _lib.CG_EINVAL
+    assert (r.value, c.value) == _lib.tile_shape(tile)
+  assert lib.cg_tile_shape(len(tiles), None, None) == _lib.CG_EINVAL
 
 
 def test_no_cpu_fallback_without_device():

@@ -86,7 +86,8 @@ def test_conv_fwd_bitexact(nB, L, Ci, Co, k, seg, use_shift):
   assert float(got[:, :, Co:].abs().max()) == 0.0 if cop > Co else True
 
 
-ALL_TILES = [(t, ks) for t in sorted(_lib.TILES) for ks in (2, 4)]
+ALL_TILES = ([(t, ks) for t in sorted(_lib.TILES) for ks in (2, 4)] +
+             [(t, 2) for t in sorted(_lib.SWP_TILES)])
 
 
 def _force_tile(d, tile, ks, sp=0):
@@ -227,7 +228,7 @@ def test_conv_dgrad_every_tile(tile, ks, nB, L, Ci, Co, k):
                   Ci, L, cip, ck, y_stride=2, y_off=0, out_f32=True, nphase=2,
                   w_phase_stride=op.elems, off_phase_step=offs[1] - offs[0],
                   yoff_phase_step=1)
-  rows, _, _ = _lib.TILES[tile]
+  rows, _ = _lib.tile_shape(tile)
   ssq = None
   if L // 2 >= rows:  # one sample per tile: the sum of squares can be fused
     ssq = torch.zeros(nB, dtype=torch.float32, device=H.DEV)

@@ -2,7 +2,8 @@
 """Micro-benchmark of single cg_swconv / cg_wgrad launches (development tool).
 
   python tools/bench_conv.py conv  R taps nB Lx Cx N [CK] [small] [epi] [f32]
-                                   [ksteps] [rowsumsq]
+                                   [ksteps] [rowsumsq] [sp]
+(stride-2 operands are packed parity-major; sp = 1: split-parity staging)
   python tools/bench_conv.py wgrad R taps nB Lx Cx Cg [nsplit]
 Lx is the source length; outputs Lu = Lx/2 (R=2) or Lx (R=1, 2 phases when
 taps > 1)."""
@@ -44,6 +45,7 @@ def main():
     f32 = a[9] if len(a) > 9 else 0
     ksteps = a[10] if len(a) > 10 else 0
     ssq = torch.zeros(nB, device=dev) if len(a) > 11 and a[11] else None
+    sp = a[12] if len(a) > 12 else 0
     nphase = 2 if (R == 1 and taps > 1) else 1
     Lu = Lx // 2 if R == 2 else Lx
     Ly = Lu * (2 if nphase == 2 else 1)
@@ -53,7 +55,7 @@ def main():
     x = torch.randn(nB, Lx, Cx, device=dev).to(BF16)
     W = torch.randn(taps, Cx, N, device=dev)
     op = nets.PackedOperand(W, [(0, 1, Cx * N, N, 1)] * nphase, Cx, N, Cx, CK,
-                            taps)
+                            taps, parity_major=R == 2)
     op.repack()
     y = torch.zeros(nB, Ly, Cy, device=dev,
                     dtype=torch.float32 if f32 else BF16)
@@ -63,10 +65,13 @@ def main():
                         y_stride=nphase, bias=bias, epilogue=epi,
                         mask_src=y if epi == 2 else None, out_f32=bool(f32),
                         nphase=nphase, w_phase_stride=op.elems,
-                        off_phase_step=1, yoff_phase_step=1, rowsumsq=ssq)
+                        off_phase_step=1, yoff_phase_step=1, rowsumsq=ssq,
+                        w_parity_major=R == 2)
     if small >= 0:
       d.tile = small
-    d.stage_ksteps = ksteps
+      d.stage_ksteps = ksteps
+      d.split_parity = sp
+      d.ksplit = 0
     st = nets._stream()
     t = timeit(lambda: _lib.call('cg_swconv', ctypes.byref(d), st))
     fl = 2.0 * nB * Lu * N * taps * Cx * nphase

@@ -34,6 +34,11 @@ for fam, d in res.items():
     # is exact for 16-B-per-lane stores and float atomics.  Units: KiB.
     out[fam] = dict(launches=n, fetch_kib_raw=fetch_kb, write_kib=write_kb,
                     hbm_bytes_per_launch=(2 * fetch_kb + write_kb) * 1024)
+import subprocess
+try:
+    out['commit'] = open('gpurun_out/HEAD_COMMIT').read().strip()
+except OSError:
+    out['commit'] = None
 print(json.dumps(out, indent=1))
 json.dump(out, open('gpurun_out/pmc_traffic.json', 'w'), indent=1)
 PY
