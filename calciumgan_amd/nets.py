@@ -291,13 +291,21 @@ _TUNE_LOG = __import__('os').environ.get('CALCIUMGAN_TUNE_LOG')
 _SWP_TILES = __import__('os').environ.get('CALCIUMGAN_SWP_TILES', '1') != '0'
 
 
-def _load_tile_cache():
+def load_tile_cache(path):
+  """Merge a saved tile table (CALCIUMGAN_TILE_CACHE format) into this
+  process's choices; returns the number of geometries read."""
   import json
+  with open(path) as f:
+    table = json.load(f)
+  for k, v in table.items():
+    _TILE_CACHE[tuple(int(t) for t in k.split(','))] = tuple(v)
+  return len(table)
+
+
+def _load_tile_cache():
   import os
   if _TILE_CACHE_FILE and os.path.exists(_TILE_CACHE_FILE):
-    with open(_TILE_CACHE_FILE) as f:
-      for k, v in json.load(f).items():
-        _TILE_CACHE[tuple(int(t) for t in k.split(','))] = tuple(v)
+    load_tile_cache(_TILE_CACHE_FILE)
 
 
 def _save_tile_cache():
