@@ -10,6 +10,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CALCIUMGAN_HIP_LIB points at another build of the same C ABI (development)
 LIB_PATH = os.environ.get('CALCIUMGAN_HIP_LIB') or os.path.join(
     _HERE, 'csrc', 'libcalciumgan_hip.so')
+# the same sources with fp16 activations: the reference's mixed_float16 mode
+LIB_PATH_F16 = os.environ.get('CALCIUMGAN_HIP_LIB_F16') or os.path.join(
+    _HERE, 'csrc', 'libcalciumgan_hip_f16.so')
+DTYPE_BF16, DTYPE_F16 = 0, 1
 
 CG_EINVAL = 100001
 EPI_NONE, EPI_LRELU, EPI_MASK, EPI_SIGMOID, EPI_LN_LRELU = 0, 1, 2, 3, 4
@@ -84,6 +88,7 @@ class WgradDesc(C.Structure):
       ('Cx_real', c_i), ('Cg_real', c_i),
       ('nsplit', c_i),
       ('tile_rows', c_i),
+      ('no_xcd_group', c_i),
       ('dbias', c_vp),
       ('bias_rows', c_ll),
       ('partials', c_vp),
@@ -94,6 +99,7 @@ class WgradDesc(C.Structure):
 # name -> argtypes (restype is int unless listed in _RESTYPES)
 SIGNATURES = {
     'cg_abi_version': [],
+    'cg_act_dtype': [],
     'cg_struct_size': [c_i],
     'cg_tile_shape': [c_i, C.POINTER(c_i), C.POINTER(c_i)],
     'cg_profile_enable': [c_i],
@@ -135,35 +141,57 @@ SIGNATURES = {
     'cg_lrelu_bwd': [c_vp, c_vp, c_vp, c_ll, c_f, c_vp],
     'cg_adam': [c_vp, c_vp, c_vp, c_vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_vp,
                 c_vp],
+    'cg_grad_finite': [c_vp, c_ll, c_vp, c_vp],
+    'cg_adam_scaled': [c_vp, c_vp, c_vp, c_vp, c_ll, c_f, c_f, c_f, c_f, c_f,
+                       c_vp, c_vp],
+    'cg_loss_scale_update': [c_vp, c_i, c_vp],
     'cg_signal_metrics': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_f, c_f,
                           c_vp],
 }
 _RESTYPES = {'cg_packed_elems': c_ll, 'cg_pack_plan_bytes': c_ll,
              'cg_pack_plan_build': c_ll, 'cg_wgrad_partials_elems': c_ll}
 
-_lib = None
+_libs = {}       # precision -> ctypes handle
+_active = 'bf16'  # precision of the library `call` / `load()` address
 
 
 class HipLibraryError(RuntimeError):
   pass
 
 
-def load():
-  """Load (once) and return the ctypes handle.  Raises HipLibraryError when the
-  library has not been built -- there is deliberately no fallback path."""
-  global _lib
-  if _lib is not None:
-    return _lib
-  if not os.path.exists(LIB_PATH):
+def use(precision):
+  """Select the build every later `call` / `load()` goes to: 'bf16' (default)
+  or 'f16' (mixed_float16).  The two builds keep separate kernels and tuning
+  tables; objects created under one precision must be driven under it (the
+  algorithm object checks)."""
+  global _active
+  if precision not in ('bf16', 'f16'):
+    raise ValueError("precision must be 'bf16' or 'f16'")
+  load(precision)
+  _active = precision
+
+
+def active():
+  return _active
+
+
+def load(precision=None):
+  """Load (once per precision) and return the ctypes handle.  Raises
+  HipLibraryError when the library has not been built -- there is deliberately
+  no fallback path."""
+  precision = precision or _active
+  if precision in _libs:
+    return _libs[precision]
+  path = LIB_PATH_F16 if precision == 'f16' else LIB_PATH
+  if not os.path.exists(path):
     raise HipLibraryError(
         'calciumgan_amd: {} not found. Build it with `python -m '
         'calciumgan_amd.build` (hipcc --offload-arch=gfx950); there is no '
-        'CPU fallback.'.format(LIB_PATH))
+        'CPU fallback.'.format(path))
   try:
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
   except OSError as e:
-    raise HipLibraryError('calciumgan_amd: cannot load {}: {}'.format(
-        LIB_PATH, e))
+    raise HipLibraryError('calciumgan_amd: cannot load {}: {}'.format(path, e))
   for name, argtypes in SIGNATURES.items():
     fn = getattr(lib, name)  # AttributeError if the symbol is missing
     fn.argtypes = argtypes
@@ -174,8 +202,13 @@ def load():
       raise HipLibraryError(
           'calciumgan_amd: {} is {} bytes here, {} in {} -- stale build or '
           'binding (rebuild with `python -m calciumgan_amd.build`)'.format(
-              cls.__name__, C.sizeof(cls), lib.cg_struct_size(which), LIB_PATH))
-  _lib = lib
+              cls.__name__, C.sizeof(cls), lib.cg_struct_size(which), path))
+  want = DTYPE_F16 if precision == 'f16' else DTYPE_BF16
+  if lib.cg_act_dtype() != want:
+    raise HipLibraryError(
+        'calciumgan_amd: {} computes with dtype {} (wanted {})'.format(
+            path, lib.cg_act_dtype(), want))
+  _libs[precision] = lib
   return lib
 
 
@@ -187,6 +220,7 @@ def check(rc, what):
 
 
 def call(name, *args):
-  """Invoke an int-returning entry point and raise on a non-zero code."""
+  """Invoke an int-returning entry point of the active build and raise on a
+  non-zero code."""
   rc = getattr(load(), name)(*args)
   check(rc, name)

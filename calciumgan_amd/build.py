@@ -11,6 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libcalciumgan_hip.so')
+# the same sources with fp16 activations (-DCG_ACT_F16=1): mixed_float16 mode
+LIB_F16 = os.path.join(CSRC, 'libcalciumgan_hip_f16.so')
 SOURCES = ['swconv.hip', 'swconv_swp.hip', 'wgrad.hip', 'pointwise.hip',
            'dense_rows.hip']
 HEADERS = ['cg_common.h', 'swconv_args.h', os.path.join('..', '..', 'include',
@@ -25,34 +27,47 @@ def _hipcc():
   raise RuntimeError('hipcc not found')
 
 
-def needs_build():
-  if not os.path.exists(LIB):
+def needs_build(lib=LIB):
+  if not os.path.exists(lib):
     return True
-  t = os.path.getmtime(LIB)
+  t = os.path.getmtime(lib)
   deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
   return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-  if not force and not needs_build():
-    return LIB
-  objs = []
+def _build_one(lib, defines, suffix, verbose):
+  from concurrent.futures import ThreadPoolExecutor
+  jobs = []
   for src in SOURCES:
-    obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-    cmd = [
+    obj = os.path.join(CSRC, src.replace('.hip', suffix + '.o'))
+    jobs.append(([
         _hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
-        '-Wall', '-Wno-unused-function', '-c',
-        os.path.join(CSRC, src), '-o', obj
-    ]
+        '-Wall', '-Wno-unused-function'
+    ] + defines + ['-c', os.path.join(CSRC, src), '-o', obj], obj))
+
+  def run(job):
     if verbose:
-      print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    objs.append(obj)
-  cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB
+      print(' '.join(job[0]), flush=True)
+    subprocess.check_call(job[0])
+    return job[1]
+
+  # (a few translation units, the largest a minute of hipcc: compile together)
+  with ThreadPoolExecutor(max_workers=4) as pool:
+    objs = list(pool.map(run, jobs))
+  cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib
         ] + objs
   if verbose:
     print(' '.join(cmd), flush=True)
   subprocess.check_call(cmd)
+
+
+def build(force=False, verbose=True):
+  """Both builds of the kernel library: bf16 activations (LIB) and fp16
+  activations (LIB_F16, -DCG_ACT_F16=1)."""
+  if force or needs_build(LIB):
+    _build_one(LIB, [], '', verbose)
+  if force or needs_build(LIB_F16):
+    _build_one(LIB_F16, ['-DCG_ACT_F16=1'], '.f16', verbose)
   return LIB
 
 

@@ -6,7 +6,25 @@
 
 #include "../../include/calciumgan_hip.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// Storage type of activations / activation gradients / packed MFMA operands:
+// bf16 (default build, libcalciumgan_hip.so) or IEEE fp16 (-DCG_ACT_F16=1,
+// libcalciumgan_hip_f16.so: the reference's mixed_float16 policy, main.py:22-30).
+// Same sources, same C ABI; accumulation, statistics, losses and the master
+// weights are f32 in both.
+#ifndef CG_ACT_F16
+#define CG_ACT_F16 0
+#endif
+#if CG_ACT_F16
+typedef _Float16 act_scalar;
+typedef __attribute__((ext_vector_type(8))) _Float16 act8;
+#define cg_mfma_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define cg_mfma_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
+typedef __bf16 act_scalar;
+typedef __attribute__((ext_vector_type(8))) __bf16 act8;
+#define cg_mfma_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define cg_mfma_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -35,18 +53,29 @@ bool cg_prof_next(int family, hipEvent_t* start, hipEvent_t* stop);
       hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);       \
   } while (0)
 
-__device__ __forceinline__ float bf2f(uint16_t v) {
+__device__ __forceinline__ float act2f(uint16_t v) {
+#if CG_ACT_F16
+  return (float)__builtin_bit_cast(_Float16, v);
+#else
   return __uint_as_float(((uint32_t)v) << 16);
+#endif
 }
 
-// round-to-nearest-even f32 -> bf16 (plain cast keeps NaN a NaN on gfx950)
-__device__ __forceinline__ uint16_t f2bf(float f) {
-  __bf16 b = (__bf16)f;
+// round-to-nearest-even f32 -> bf16 / fp16 (a plain cast keeps NaN a NaN on
+// gfx950; fp16 overflows to infinity, which the loss scaler looks for)
+__device__ __forceinline__ uint16_t f2act(float f) {
+  act_scalar b = (act_scalar)f;
   return __builtin_bit_cast(uint16_t, b);
 }
 
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+// the two activations of one 32-bit word
+__device__ __forceinline__ float act_lo(uint32_t w) { return act2f((uint16_t)w); }
+__device__ __forceinline__ float act_hi(uint32_t w) {
+  return act2f((uint16_t)(w >> 16));
+}
+
+__device__ __forceinline__ uint32_t pack2act(float lo, float hi) {
+  return (uint32_t)f2act(lo) | ((uint32_t)f2act(hi) << 16);
 }
 
 // PhaseShuffle source row (reference gan/models/calciumgan.py:117-138):

@@ -38,12 +38,12 @@ __global__ __launch_bounds__(kDrThreads, 2) void dense_rows_kernel(
   const int g = lane >> 4;
   // all of W as B fragments: fragment (ks, nt) = 8 k-values of column
   // nt*16 + r16, k-group g of K-step ks
-  bf16x8 wf[KSTEPS][8];
+  act8 wf[KSTEPS][8];
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
-      wf[ks][nt] = *reinterpret_cast<const bf16x8*>(
+      wf[ks][nt] = *reinterpret_cast<const act8*>(
           a.w + (((long long)(nt * 16 + r16) * KSTEPS + ks) * 16 + g) * 8);
   float* tl = tile[wave];
   // read-back map of the transpose tile: lane -> (row lane>>5 of a 2-row
@@ -63,18 +63,18 @@ __global__ __launch_bounds__(kDrThreads, 2) void dense_rows_kernel(
   const long long nblk = (a.rows + 15) / 16;
   const long long stride = (long long)gridDim.x * 4;
   long long blk = (long long)blockIdx.x * 4 + wave;
-  auto load_a = [&](long long b, bf16x8 (&dst)[KSTEPS]) {
+  auto load_a = [&](long long b, act8 (&dst)[KSTEPS]) {
     const long long row = b * 16 + r16;
     const bool ok = b < nblk && row < a.rows;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      act8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       if (ok)
-        v = *reinterpret_cast<const bf16x8*>(a.x + row * a.Cx + ks * 32 + g * 8);
+        v = *reinterpret_cast<const act8*>(a.x + row * a.Cx + ks * 32 + g * 8);
       dst[ks] = v;
     }
   };
-  auto compute = [&](long long b, const bf16x8 (&af)[KSTEPS]) {
+  auto compute = [&](long long b, const act8 (&af)[KSTEPS]) {
     f32x4 acc[8];
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kDrThreads, 2) void dense_rows_kernel(
     for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], wf[ks][nt],
+        acc[nt] = cg_mfma_16x16x32(af[ks], wf[ks][nt],
                                                           acc[nt], 0, 0, 0);
     // accumulator (row 4g + r, column nt*16 + r16) -> LDS tile -> row-major
 #pragma unroll
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kDrThreads, 2) void dense_rows_kernel(
   };
   // two statically named fragment sets (a runtime-indexed register array
   // would live in scratch): the next block's loads fly during this block
-  bf16x8 af0[KSTEPS], af1[KSTEPS];
+  act8 af0[KSTEPS], af1[KSTEPS];
   load_a(blk, af0);
   while (blk < nblk) {
     load_a(blk + stride, af1);

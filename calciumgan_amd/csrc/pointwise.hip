@@ -20,8 +20,8 @@ __device__ __forceinline__ void unpack8(const uint4 u, float* v) {
   const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    v[2 * i] = __uint_as_float(w[i] << 16);
-    v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    v[2 * i] = act_lo(w[i]);
+    v[2 * i + 1] = act_hi(w[i]);
   }
 }
 __device__ __forceinline__ uint4 ldg16(const uint16_t* p) {
@@ -32,8 +32,8 @@ __device__ __forceinline__ void load8(const uint16_t* p, float* v) {
 }
 __device__ __forceinline__ void store8(uint16_t* p, const float* v) {
   *reinterpret_cast<uint4*>(p) =
-      make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]),
-                 pack2bf(v[6], v[7]));
+      make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]), pack2act(v[4], v[5]),
+                 pack2act(v[6], v[7]));
 }
 
 // 8 consecutive f32 channels of a row whose pitch is `pitch` floats, with the
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         o[e] = (c0 + e < C) ? rstd * (dyh[e] - s1 - xh[e] * s2) : 0.f;
-        accd[e] += bf2f(f2bf(o[e]));  // bias gradient of the producing conv
+        accd[e] += act2f(f2act(o[e]));  // bias gradient of the producing conv
       }
       store8(dy + row * Cp + c0, o);
     }
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kThreads) void dense1_fwd_kernel(
       float v[8];
       unpack8(raw[k], v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[e] * bf2f(f2bf(wv[k][e]));
+      for (int e = 0; e < 8; ++e) s += v[e] * act2f(f2act(wv[k][e]));
     }
   }
   s = wave_sum(s);
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void dense1_bwd_kernel(
   unpack8(raw, vh);
 #pragma unroll
   for (int e = 0; e < 8; ++e)
-    o[e] = (ch + e < C) ? c * bf2f(f2bf(wv[e])) * (vh[e] > 0.f ? 1.f : alpha)
+    o[e] = (ch + e < C) ? c * act2f(f2act(wv[e])) * (vh[e] > 0.f ? 1.f : alpha)
                         : 0.f;
   store8(delta + (long long)b * F + i, o);
 }
@@ -667,6 +667,56 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(
   m[i] = mi;
   v[i] = vi;
   p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
+// ---- dynamic loss scaling (mixed_float16: optimizer.py:10-12,23-29) ---------
+// state ls[4] = {scale S, consecutive finite steps, applied Adam steps t,
+// "gradients finite" flag of the update in progress (1 between updates)}
+__global__ __launch_bounds__(kThreads) void grad_finite_kernel(
+    const float* __restrict__ grad, long long n4, float* __restrict__ ls) {
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * kThreads) {
+    const f32x4 g = reinterpret_cast<const f32x4*>(grad)[i];
+    bad |= !(__builtin_isfinite(g[0]) && __builtin_isfinite(g[1]) &&
+             __builtin_isfinite(g[2]) && __builtin_isfinite(g[3]));
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) ls[3] = 0.f;  // (only ever 0)
+}
+
+__global__ __launch_bounds__(kThreads) void adam_ls_kernel(
+    float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
+    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+    float gscale, const float* __restrict__ ls) {
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  if (ls[3] == 0.f) return;  // non-finite gradients: the update is skipped
+  const float t = ls[2] + 1.f;
+  const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  const float g = grad[i] * (gscale / ls[0]);
+  const float mi = b1 * m[i] + (1.f - b1) * g;
+  const float vi = b2 * v[i] + (1.f - b2) * g * g;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
+__global__ void loss_scale_update_kernel(float* __restrict__ ls, float interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (ls[3] != 0.f) {
+    ls[2] += 1.f;
+    if (ls[1] + 1.f >= interval) {
+      const float s2 = ls[0] * 2.f;
+      if (__builtin_isfinite(s2)) ls[0] = s2;  // (stays put once doubling overflows)
+      ls[1] = 0.f;
+    } else {
+      ls[1] += 1.f;
+    }
+  } else {
+    ls[0] = fmaxf(ls[0] * 0.5f, 1.f);
+    ls[1] = 0.f;
+  }
+  ls[3] = 1.f;
 }
 
 // min/max/mean/std over the channels of each (b,t) row of real and of fake,
@@ -1037,6 +1087,33 @@ extern "C" int cg_adam(float* p, const float* grad, float* m, float* v,
   hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, kThreads, 1LL << 31)),
                      dim3(kThreads), 0, S_(stream), p, grad, m, v, n, lr_t,
                      beta1, beta2, eps, grad_scale, lr_t_dev);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_grad_finite(const float* grad, long long n, float* ls,
+                              void* stream) {
+  if (n < 4 || (n & 3)) return CG_EINVAL;
+  hipLaunchKernelGGL(grad_finite_kernel, dim3(grid1d(n / 4, kThreads, 2048)),
+                     dim3(kThreads), 0, S_(stream), grad, n / 4, ls);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_adam_scaled(float* p, const float* grad, float* m, float* v,
+                              long long n, float lr, float beta1, float beta2,
+                              float eps, float grad_scale, const float* ls,
+                              void* stream) {
+  if (n < 1 || !ls) return CG_EINVAL;
+  hipLaunchKernelGGL(adam_ls_kernel, dim3(grid1d(n, kThreads, 1LL << 31)),
+                     dim3(kThreads), 0, S_(stream), p, grad, m, v, n, lr, beta1,
+                     beta2, eps, grad_scale, ls);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_loss_scale_update(float* ls, int growth_interval,
+                                    void* stream) {
+  if (!ls || growth_interval < 1) return CG_EINVAL;
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, S_(stream),
+                     ls, (float)growth_interval);
   CG_LAUNCH_CHECK();
 }
 

@@ -356,7 +356,7 @@ swconv_kernel(ConvArgs a) {
         // read to just before its use and waits on it with lgkmcnt(0): ~one
         // exposed LDS round trip per four MFMAs).  The stage then runs as
         // "all reads, one wait, 16*KS MFMAs back to back".
-        bf16x8 afrag[2][KH][MT], bfrag[2][KH][NT];
+        act8 afrag[2][KH][MT], bfrag[2][KH][NT];
         auto read_frags = [&](int buf, int ks) {
           const int ti = tap < a.taps ? tap : a.taps - 1;  // padded K: B is zero
           int aoff;
@@ -387,11 +387,11 @@ swconv_kernel(ConvArgs a) {
                 aoff = (reg + idx) * a.pitchA;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                  bfrag[buf][kh][nt] = *reinterpret_cast<const bf16x8*>(
+                  bfrag[buf][kh][nt] = *reinterpret_cast<const act8*>(
                       curB + nt * MF * kRowB + boff[ks][kh]);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                  afrag[buf][kh][mt] = *reinterpret_cast<const bf16x8*>(
+                  afrag[buf][kh][mt] = *reinterpret_cast<const act8*>(
                       ldsA + rowbase[mt] + aoff);
               }
               return;
@@ -401,11 +401,11 @@ swconv_kernel(ConvArgs a) {
           for (int kh = 0; kh < KH; ++kh) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              bfrag[buf][kh][nt] = *reinterpret_cast<const bf16x8*>(
+              bfrag[buf][kh][nt] = *reinterpret_cast<const act8*>(
                   curB + nt * MF * kRowB + boff[ks][kh]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-              afrag[buf][kh][mt] = *reinterpret_cast<const bf16x8*>(
+              afrag[buf][kh][mt] = *reinterpret_cast<const act8*>(
                   ldsA + (rowbase[mt] + goff) + aoff + kh * 16);
           }
           q8l += 4;
@@ -430,11 +430,11 @@ swconv_kernel(ConvArgs a) {
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
                 if constexpr (MF == 16)
-                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  acc[mt][nt] = cg_mfma_16x16x32(
                       afrag[ks & 1][kh][mt], bfrag[ks & 1][kh][nt],
                       acc[mt][nt], 0, 0, 0);
                 else
-                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  acc[mt][nt] = cg_mfma_32x32x16(
                       afrag[ks & 1][kh][mt], bfrag[ks & 1][kh][nt],
                       acc[mt][nt], 0, 0, 0);
               }
@@ -523,7 +523,7 @@ swconv_kernel(ConvArgs a) {
             const int n = (e < 4 ? nA : nB - 4) + e;
             // statistics of the STORED (bf16) pre-activation, as the separate
             // cg_ln_lrelu_fwd pass sees it
-            v[e] = n < a.N ? bf2f(f2bf(v[e] + bv[e])) : 0.f;
+            v[e] = n < a.N ? act2f(f2act(v[e] + bv[e])) : 0.f;
             s1 += v[e];
             s2 += v[e] * v[e];
           }
@@ -565,11 +565,11 @@ swconv_kernel(ConvArgs a) {
             if (a.ln_mean)
               *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.y) + rowoff +
                                         nA) =
-                  make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
-                             pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+                  make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]),
+                             pack2act(v[4], v[5]), pack2act(v[6], v[7]));
             *reinterpret_cast<uint4*>(a.ln_h + rowoff + nA) =
-                make_uint4(pack2bf(hv[0], hv[1]), pack2bf(hv[2], hv[3]),
-                           pack2bf(hv[4], hv[5]), pack2bf(hv[6], hv[7]));
+                make_uint4(pack2act(hv[0], hv[1]), pack2act(hv[2], hv[3]),
+                           pack2act(hv[4], hv[5]), pack2act(hv[6], hv[7]));
             if (a.ln_mean && wn == 0 && cg8 == 0) {
               a.ln_mean[ridx] = mean;
               a.ln_rstd[ridx] = rstd;
@@ -609,7 +609,7 @@ swconv_kernel(ConvArgs a) {
           if (a.out_shifts) {
             // the unfused form stores this gradient in bf16 before masking
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+            for (int e = 0; e < 8; ++e) v[e] = act2f(f2act(v[e]));
           }
           const uint2 ha = *reinterpret_cast<const uint2*>(a.mask + rowoff + nA);
           const uint2 hb = okB ? *reinterpret_cast<const uint2*>(a.mask + rowoff + nB)
@@ -618,7 +618,7 @@ swconv_kernel(ConvArgs a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const uint16_t hv = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
-            v[e] *= (bf2f(hv) > 0.f) ? 1.f : a.alpha;
+            v[e] *= (act2f(hv) > 0.f) ? 1.f : a.alpha;
           }
         } else if (a.epilogue == CG_EPI_SIGMOID) {
 #pragma unroll
@@ -643,8 +643,8 @@ swconv_kernel(ConvArgs a) {
           uint16_t* dst =
               (to_side ? a.side : reinterpret_cast<uint16_t*>(a.y)) + rowoff + nA;
           *reinterpret_cast<uint4*>(dst) =
-              make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
-                         pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+              make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]),
+                         pack2act(v[4], v[5]), pack2act(v[6], v[7]));
         }
       }
     }
@@ -705,15 +705,15 @@ __global__ __launch_bounds__(256) void split_finish_kernel(SplitFinishArgs f) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const uint16_t hv = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
-      v[e] *= (bf2f(hv) > 0.f) ? 1.f : f.alpha;
+      v[e] *= (act2f(hv) > 0.f) ? 1.f : f.alpha;
     }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e)
     if (c + e >= f.N) v[e] = 0.f;
   *reinterpret_cast<uint4*>(f.y + e0) =
-      make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]),
-                 pack2bf(v[6], v[7]));
+      make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]), pack2act(v[4], v[5]),
+                 pack2act(v[6], v[7]));
 }
 
 // ---------------------------------------------------------------------------
@@ -779,8 +779,8 @@ __device__ __forceinline__ void pack_group(const PackArgs& a, long long r) {
       if (c + e < a.C_real) v[e] = src[(long long)(c + e) * a.s_c];
   }
   *reinterpret_cast<uint4*>(a.dst + r * 8) =
-      make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]),
-                 pack2bf(v[6], v[7]));
+      make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]), pack2act(v[4], v[5]),
+                 pack2act(v[6], v[7]));
 }
 
 constexpr int kPackBlock = 256 * 8;  // elements packed by one 256-thread block
@@ -814,6 +814,8 @@ inline int ilog2(int v) {
 }  // namespace
 
 extern "C" int cg_abi_version(void) { return CG_ABI_VERSION; }
+
+extern "C" int cg_act_dtype(void) { return CG_ACT_F16 ? CG_DTYPE_F16 : CG_DTYPE_BF16; }
 
 extern "C" int cg_struct_size(int which) {
   switch (which) {

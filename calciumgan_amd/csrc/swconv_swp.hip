@@ -77,7 +77,7 @@ __device__ __forceinline__ int sw64(int byte) {
 // and free) instead of in front of their first MFMA, which by then sits behind
 // the next K-step's freshly issued reads (lgkmcnt(0) there stalls on those).
 template <int N>
-__device__ __forceinline__ void landed(const bf16x8 (&f)[N]) {
+__device__ __forceinline__ void landed(const act8 (&f)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) asm volatile("" ::"v"(f[i]));
 }
@@ -257,19 +257,19 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
   const int half_taps = a.taps >> 1;
 
   // fragments of K-step ks of stage s (global index gs) of pass p
-  auto read_frags = [&](bf16x8(&af)[MT], bf16x8(&bf)[NT], int p, int s, int gs,
+  auto read_frags = [&](act8(&af)[MT], act8(&bf)[NT], int p, int s, int gs,
                         int ks) {
     const uint16_t* curB = ldsB + (gs % kSwpRing) * kBufB;
     const unsigned char* abuf = ldsA + (p & 1) * pa.abytes;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      bf[nt] = *reinterpret_cast<const bf16x8*>(curB + nt * 16 * kRowB +
+      bf[nt] = *reinterpret_cast<const act8*>(curB + nt * 16 * kRowB +
                                                 (ks ? boff[1] : boff[0]));
     if (p < full_passes) {
       const int tapoff = (s * KS + ks) * 64;  // one tap per K-step
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-        af[mt] = *reinterpret_cast<const bf16x8*>(
+        af[mt] = *reinterpret_cast<const act8*>(
             abuf + sw64(rowb0 + mt * 1024 + tapoff));
     } else {
       // narrow chunk: stage s -> parity s >> 1, K-step (s & 1) * 2 + ks; its
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
       idx = idx < half_taps ? idx : half_taps - 1;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-        af[mt] = *reinterpret_cast<const bf16x8*>(
+        af[mt] = *reinterpret_cast<const act8*>(
             abuf + sw64(rowb0 + mt * 1024 - g * 16 + idx * 64 + par * 16));
     }
   };
@@ -291,12 +291,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mfma_step = [&](const bf16x8(&af)[MT], const bf16x8(&bf)[NT]) {
+  auto mfma_step = [&](const act8(&af)[MT], const act8(&bf)[NT]) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[nt],
+        acc[mt][nt] = cg_mfma_16x16x32(af[mt], bf[nt],
                                                               acc[mt][nt], 0, 0, 0);
   };
 
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
   if (pa.total_stages > 2) issue_b(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  bf16x8 af0[MT], bf0[NT], af1[MT], bf1[NT];
+  act8 af0[MT], bf0[NT], af1[MT], bf1[NT];
   read_frags(af0, bf0, 0, 0, 0, 0);
   landed(af0);
   landed(bf0);
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
         } else if (a.epilogue == CG_EPI_MASK && !to_side) {
           if (a.out_shifts) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+            for (int e = 0; e < 8; ++e) v[e] = act2f(f2act(v[e]));
           }
           const uint2 ha = *reinterpret_cast<const uint2*>(a.mask + rowoff + nA);
           const uint2 hb = okB ? *reinterpret_cast<const uint2*>(a.mask + rowoff + nB)
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const uint16_t hv = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
-            v[e] *= (bf2f(hv) > 0.f) ? 1.f : a.alpha;
+            v[e] *= (act2f(hv) > 0.f) ? 1.f : a.alpha;
           }
         } else if (a.epilogue == CG_EPI_SIGMOID) {
 #pragma unroll
@@ -478,8 +478,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
           uint16_t* dst =
               (to_side ? a.side : reinterpret_cast<uint16_t*>(a.y)) + rowoff + nA;
           *reinterpret_cast<uint4*>(dst) =
-              make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
-                         pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+              make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]),
+                         pack2act(v[4], v[5]), pack2act(v[6], v[7]));
         }
       }
     }

@@ -37,7 +37,42 @@ struct WgradArgs {
   // instead of f32 atomics into dw; null: atomics
   float* part;
   int pgx, pgy;  // (cx, cg) block grid of the launch
+  // XCD-grouped block order (speed only): the gsz workgroups that stream the
+  // same x and / or g tiles of one K' split get linear ids that differ by 8
+  // (same XCD under round-robin placement, adjacent in dispatch order), so the
+  // tile is fetched into that XCD's L2 once.  gmode 0: group = the gx cx-blocks
+  // of one (cg block, split) [they share g]; 1: the gy cg-blocks of one (cx
+  // block, split) [they share x]; 2: all gx * gy blocks of a split; 3: plain
+  // order (bx fastest), no grouping.
+  int gmode, gsz;
 };
+
+// linear block id -> (bx, by, bz); false: padding id of the grouped order
+__device__ __forceinline__ bool wgrad_block(const WgradArgs& a, int gz, int id,
+                                            int& bx, int& by, int& bz) {
+  const int xcd = id & 7;
+  const int j = id >> 3;
+  const int member = j % a.gsz;
+  const int grp = (j / a.gsz) * 8 + xcd;
+  if (a.gmode == 0) {
+    bx = member;
+    by = grp % a.pgy;
+    bz = grp / a.pgy;
+  } else if (a.gmode == 1) {
+    by = member;
+    bx = grp % a.pgx;
+    bz = grp / a.pgx;
+  } else if (a.gmode == 2) {
+    bx = member % a.pgx;
+    by = member / a.pgx;
+    bz = grp;
+  } else {  // 3: plain order
+    bx = id % a.pgx;
+    by = (id / a.pgx) % a.pgy;
+    bz = id / (a.pgx * a.pgy);
+  }
+  return bz < gz;
+}
 
 constexpr int kPitchX = 48;  // 32 ch + 16 pad  (96 B = 32*3)
 constexpr int kPitchG = 80;  // 64 ch + 16 pad  (160 B = 32*5)
@@ -47,10 +82,10 @@ __device__ __forceinline__ s16x4 tr_read(const uint16_t* p) {
       (__attribute__((address_space(3))) s16x4*)(p));
 }
 
-__device__ __forceinline__ bf16x8 join(s16x4 lo, s16x4 hi) {
+__device__ __forceinline__ act8 join(s16x4 lo, s16x4 hi) {
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(act8, v);
 }
 
 // MFMA work of one staged tile: every wave reads its transposed fragments from
@@ -83,8 +118,8 @@ __device__ __forceinline__ void wgrad_compute(const WgradArgs& a,
                                 : tap * kPitchX;
         xl[s] = ldsX + (4 * g4 + q) * kPitchX + 4 * p + toff;
       }
-      bf16x8 bfr[2][4], afr[2];
-      auto load_b = [&](int kstep, bf16x8 (&dst)[4]) {
+      act8 bfr[2][4], afr[2];
+      auto load_b = [&](int kstep, act8 (&dst)[4]) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
           dst[nt] = join(tr_read(gl + kstep * 32 * kPitchG + nt * 16),
@@ -110,7 +145,7 @@ __device__ __forceinline__ void wgrad_compute(const WgradArgs& a,
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
-            acc[i >> 1][i & 1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            acc[i >> 1][i & 1][nt] = cg_mfma_16x16x32(
                 afr[i & 1], bfr[kstep & 1][nt], acc[i >> 1][i & 1][nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -124,7 +159,7 @@ __device__ __forceinline__ void wgrad_compute(const WgradArgs& a,
     // tile rows of this lane's two transposed reads (k = 8*g4 + 4*h + q')
     const int i0 = rbase + 4 * g4 + q;
     const int i1 = i0 + 16;
-    bf16x8 bfrag[4];
+    act8 bfrag[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
       bfrag[nt] = join(tr_read(ldsG + i0 * kPitchG + nt * 16 + 4 * p),
@@ -142,12 +177,12 @@ __device__ __forceinline__ void wgrad_compute(const WgradArgs& a,
           toff = tap * kPitchX;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          const bf16x8 afrag =
+          const act8 afrag =
               join(tr_read(ldsX + x0 + toff + mt * 16 + 4 * p),
                    tr_read(ldsX + x1 + toff + mt * 16 + 4 * p));
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
-            acc[s][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            acc[s][mt][nt] = cg_mfma_16x16x32(
                 afrag, bfrag[nt], acc[s][mt][nt], 0, 0, 0);
         }
       }
@@ -171,8 +206,8 @@ __device__ __forceinline__ void colsum_tile(const uint16_t* ldsG, int m0,
     if (m0 + row < bias_rows) {
       const uint32_t w =
           *reinterpret_cast<const uint32_t*>(ldsG + row * kPitchG + cp);
-      s0 += __uint_as_float(w << 16);
-      s1 += __uint_as_float(w & 0xffff0000u);
+      s0 += act_lo(w);
+      s1 += act_hi(w);
     }
   }
 }
@@ -405,9 +440,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
 }
 
 template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, bool ALLT>
-__global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
-  wgrad_body<R, TPW, ROWSPLIT, PIPE, TT, ALLT>(a, blockIdx.x, blockIdx.y,
-                                               blockIdx.z, gridDim.z);
+__global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a, int gz) {
+  int bx, by, bz;
+  if (!wgrad_block(a, gz, blockIdx.x, bx, by, bz)) return;
+  wgrad_body<R, TPW, ROWSPLIT, PIPE, TT, ALLT>(a, bx, by, bz, gz);
 }
 
 // Second stage of the partial-sum path: thread (block tile, slot, tid) sums its
@@ -478,12 +514,9 @@ struct WgradMulti {
 template <int R, int TPW>
 __global__ __launch_bounds__(512) void wgrad_multi_kernel(WgradMulti m) {
   for (int li = 0; li < m.n; ++li) {
-    const int gx = m.gx[li], gy = m.gy[li], gz = m.gz[li];
-    const int id = blockIdx.x;
-    if (id < gx * gy * gz) {
-      const int bx = id % gx;
-      const int by = (id / gx) % gy;
-      const int bz = id / (gx * gy);
+    const int gz = m.gz[li];
+    int bx, by, bz;
+    if (wgrad_block(m.a[li], gz, blockIdx.x, bx, by, bz)) {
       if (m.tt[li] == 128)
         wgrad_body<R, TPW, false, true, 128, true>(m.a[li], bx, by, bz, gz);
       else
@@ -499,6 +532,15 @@ inline int ilog2(int v) {
   return l;
 }
 
+// linear grid of the XCD-grouped block order: whole groups, a multiple of 8 of
+// them (padding ids return at once)
+inline unsigned wgrad_grid(const WgradArgs& a, int gz) {
+  if (a.gmode == 3) return (unsigned)(a.pgx * a.pgy * gz);
+  const int per_split = a.pgx * a.pgy / a.gsz;  // groups per K' split
+  const int groups = per_split * gz;
+  return (unsigned)((groups + 7) / 8 * 8 * a.gsz);
+}
+
 template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, bool ALLT = false>
 int launch_wgrad1(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
@@ -511,7 +553,7 @@ int launch_wgrad1(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     attr_set = true;
   }
   CG_LAUNCH_PROF(CG_FAMILY_WGRAD, (wgrad_kernel<R, TPW, ROWSPLIT, PIPE, TT, ALLT>),
-                 grid, dim3(512), lds, s, a);
+                 dim3(wgrad_grid(a, grid.z)), dim3(512), lds, s, a, (int)grid.z);
   CG_LAUNCH_CHECK();
 }
 
@@ -607,6 +649,24 @@ int plan_wgrad(const cg_wgrad_desc* d, WgradPlan& p) {
   p.tpw = rowsplit ? 1 : (d->taps <= 8 ? 1 : (d->taps <= 16 ? 2 : 3));
   a.part = nullptr;
   a.pgx = p.gx; a.pgy = p.gy;
+  // XCD grouping: a group must pack the 32 CUs of an XCD (size divides 32);
+  // among the feasible groupings the one with the least re-read bytes
+  {
+    auto fits = [](int n) { return n >= 1 && n <= 32 && 32 % n == 0; };
+    const double xb = (double)d->nB * d->Lx * d->Cx, gb = (double)a.M * d->Cg;
+    a.gmode = 3; a.gsz = 1;
+    double best = xb * p.gy + gb * p.gx;  // no sharing
+    if (fits(p.gx) && xb * p.gy + gb < best) {
+      best = xb * p.gy + gb; a.gmode = 0; a.gsz = p.gx;
+    }
+    if (fits(p.gy) && xb + gb * p.gx < best) {
+      best = xb + gb * p.gx; a.gmode = 1; a.gsz = p.gy;
+    }
+    if (fits(p.gx * p.gy) && !d->no_xcd_group) {
+      a.gmode = 2; a.gsz = p.gx * p.gy;
+    }
+    if (d->no_xcd_group) { a.gmode = 3; a.gsz = 1; }
+  }
   p.part_elems = (rowsplit || nsplit < 2)
                      ? 0
                      : (long long)p.gx * p.gy * nsplit * p.tpw * 8 * 2048;
@@ -716,7 +776,7 @@ extern "C" int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream)
     const WgradPlan& p = plans[i];
     m.a[i] = p.a;
     m.gx[i] = p.gx; m.gy[i] = p.gy; m.gz[i] = p.nsplit; m.tt[i] = p.TT;
-    const int nb = p.gx * p.gy * p.nsplit;
+    const int nb = (int)wgrad_grid(p.a, p.nsplit);
     if (nb > blocks) blocks = nb;
     if (2 * p.lds > lds) lds = 2 * p.lds;
   }

@@ -27,10 +27,15 @@ class GAN(object):
     if not hparams.normalize:
       self._signals_min, self._signals_max = 0.0, 1.0
 
-    self.gen_optimizer = Optimizer(hparams)
-    self.dis_optimizer = Optimizer(hparams)
-
     self.device = generator.net.device
+    # the build of the kernel library both models compute with ('f16' under
+    # hparams.mixed_precision); every entry point re-selects it
+    self.precision = generator.net.precision
+    if discriminator.net.precision != self.precision:
+      raise ValueError('generator and discriminator differ in precision')
+    self.gen_optimizer = Optimizer(hparams, self.device)
+    self.dis_optimizer = Optimizer(hparams, self.device)
+
     self._sync = parallel.GradSync()
     self._streams = parallel.RandomStreams(_SEED, self.device, hparams.m)
     self._metrics_buf = torch.zeros(4, dtype=torch.float32, device=self.device)

@@ -86,8 +86,28 @@ class WGAN_GP(GAN):
       st['critic'].build_jvp(2)
       st['gen'].coef.copy_(torch.tensor([-1.0 / B]))
       st['gen'].bias_coef.zero_()
+      if self.dis_optimizer.loss_scale is not None:
+        # mixed_float16: the seeds of the backward chains carry the loss scale
+        # (get_scaled_loss, wgan_gp.py:32,76).  The x^ segment's chain is the
+        # INNER gradient of the penalty (its own tape, wgan_gp.py:45-48): its
+        # seed stays 1, the scale enters its second backward through v
+        st['coef_base'] = dict(
+            critic=(st['critic'].coef.clone(), st['critic'].bias_coef.clone(),
+                    torch.tensor([1.0, 1.0, 0.0], device=dev)),
+            gen=(st['gen'].coef.clone(), st['gen'].bias_coef.clone(),
+                 torch.tensor([1.0], device=dev)))
       self._state[B] = st
     return st
+
+  def _scale_seeds(self, st, which, optimizer):
+    """coef = base * (S where the segment's loss term is scaled, else 1)."""
+    S = optimizer.loss_scale
+    if S is None:
+      return
+    coef, bias_coef, scaled = st['coef_base'][which]
+    f = scaled * S + (1.0 - scaled)
+    torch.mul(coef, f, out=st[which].coef)
+    torch.mul(bias_coef, f, out=st[which].bias_coef)
 
   # -- losses (API parity; the fused kernels compute the same values) ---------
   def generator_loss(self, fake_output):
@@ -104,6 +124,7 @@ class WGAN_GP(GAN):
     plan = st['critic']
     s = nets._stream()
     plan.shifts.copy_(shifts, non_blocking=True)
+    self._scale_seeds(st, 'critic', self.dis_optimizer)
     if fake is None:
       fake = st['gws'].forward(z, keep=False)
     _lib.call('cg_interp_pack', nets._p(real), nets._p(fake), nets._p(alpha),
@@ -121,6 +142,8 @@ class WGAN_GP(GAN):
       _lib.call('cg_rownorm', nets._p(plan.gin), nets._p(norm), B, n, s)
     _lib.call('cg_gp_finalize', nets._p(norm), nets._p(st['gp'][slot:]),
               nets._p(st['coef_gp']), B, self.penalty, squared, s)
+    if self.dis_optimizer.loss_scale is not None:
+      st['coef_gp'].mul_(self.dis_optimizer.loss_scale)  # d(S * lambda * gp)/dg
     st['norm_out'] = norm
     _lib.call('cg_critic_loss', nets._p(st['dws'].d_out),
               nets._p(st['gp'][slot:]), self.penalty,
@@ -223,6 +246,7 @@ class WGAN_GP(GAN):
       shifts = torch.as_tensor(r['shifts'], dtype=torch.int32).reshape(4, 1)
     s = nets._stream()
     plan.shifts.copy_(shifts, non_blocking=True)
+    self._scale_seeds(st, 'gen', self.gen_optimizer)
     _lib.call('cg_cast_pad', nets._p(fake), nets._p(st['dws'].act[0]),
               B * lay.lin, lay.cin, self.generator.net.Cf, lay.cinp, s)
     plan.forward()
@@ -392,7 +416,7 @@ class WGAN_GP(GAN):
                 for i in range(n)],
         gen=dict(shifts_dev=g['shifts_dev'][12 * n:].view(4, 1)))
     segs, out = self._segments(g['real'], rand, g['lr_dev'])
-    it_d, it_g = self.dis_optimizer.iterations, self.gen_optimizer.iterations
+    it_d, it_g = (self.dis_optimizer.host_steps, self.gen_optimizer.host_steps)
     graphs = []
     pool = None
     torch.cuda.synchronize()
@@ -409,7 +433,7 @@ class WGAN_GP(GAN):
         graphs.append((graph.replay, grad, wait))
     finally:
       # capture only records: undo the host-side step counters it advanced
-      self.dis_optimizer.iterations, self.gen_optimizer.iterations = it_d, it_g
+      self.dis_optimizer.host_steps, self.gen_optimizer.host_steps = it_d, it_g
     g['graphs'] = graphs
     g['out'] = out['value']
     return g
@@ -434,8 +458,8 @@ class WGAN_GP(GAN):
     g['real'].copy_(real)
     self._stage_host_inputs(g)
     self._run_segments(g['graphs'], lambda replay: replay())
-    self.dis_optimizer.iterations += n
-    self.gen_optimizer.iterations += 1
+    self.dis_optimizer.host_steps += n
+    self.gen_optimizer.host_steps += 1
     return self._outputs(g['out'])
 
   def _stage_host_inputs(self, g):
@@ -456,8 +480,8 @@ class WGAN_GP(GAN):
     host[12 * n:12 * n + 4] = self._streams.shifts(1).reshape(-1)
     lr = host[12 * n + 4:].view(torch.float32)
     for i in range(n):
-      lr[i] = self.dis_optimizer.lr_t(self.dis_optimizer.iterations + i + 1)
-    lr[n] = self.gen_optimizer.lr_t(self.gen_optimizer.iterations + 1)
+      lr[i] = self.dis_optimizer.lr_t(self.dis_optimizer.host_steps + i + 1)
+    lr[n] = self.gen_optimizer.lr_t(self.gen_optimizer.host_steps + 1)
     g['stage_dev'].copy_(host, non_blocking=True)
     ev = g['stage_event'][k] = torch.cuda.Event()
     ev.record()
@@ -471,6 +495,7 @@ class WGAN_GP(GAN):
     the random draws (same structure as oracle.draw_randomness) for parity
     tests.  After two eager calls per batch size the step replays as
     hipGraphs."""
+    _lib.use(self.precision)
     real = self._to_device(inputs)
     if rand is None and self._use_graph:
       st = self._get_state(real.shape[0])
@@ -482,6 +507,7 @@ class WGAN_GP(GAN):
   def validate(self, inputs, rand=None):
     """gan.py:87-90 / :58-70 with the WGAN-GP loss (inner-gradient penalty, no
     parameter update).  Returns (fake, gen_loss, dis_loss, gp, metrics)."""
+    _lib.use(self.precision)
     real = self._to_device(inputs)
     B = real.shape[0]
     st = self._get_state(B)

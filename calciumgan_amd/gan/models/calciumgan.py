@@ -11,6 +11,7 @@ import torch
 
 from ... import geometry as geo
 from ... import nets
+from ..._lib import use as _lib_use
 from .registry import register
 
 # every model of one process draws initial weights from this stream so that
@@ -67,6 +68,7 @@ class Generator(_Model):
 
   def __call__(self, noise, training=True):
     """noise (B, noise_dim) -> (B, L, C) float32 (sigmoid when normalize)."""
+    _lib_use(self.net.precision)
     noise = torch.as_tensor(noise, dtype=torch.float32).to(
         self.net.device).contiguous()
     ws = self.net.workspace(noise.shape[0])
@@ -86,6 +88,7 @@ class Discriminator(_Model):
     """signals (B, L, C) -> (B, 1) float32.  PhaseShuffle draws one shift per
     layer per call, in training and inference alike (calciumgan.py:117)."""
     net = self.net
+    _lib_use(net.precision)
     x = torch.as_tensor(signals, dtype=torch.float32).to(net.device).contiguous()
     B = x.shape[0]
     ws = net.workspace(B)

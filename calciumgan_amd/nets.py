@@ -17,6 +17,16 @@ from . import geometry as geo
 from ._lib import ConvDesc, PackDesc, WgradDesc
 
 BF16 = torch.bfloat16
+
+
+def act_dtype():
+  """torch dtype of activations / packed operands under the active build of
+  the kernel library (_lib.use): bfloat16, or float16 for mixed_float16."""
+  return torch.float16 if _lib.active() == 'f16' else torch.bfloat16
+
+
+def _precision_tag():
+  return 1 if _lib.active() == 'f16' else 0
 LEAKY_ALPHA = 0.3  # Keras LeakyReLU() default; gan/models/utils.py:6-8
 LN_EPS = 1e-3  # Keras LayerNormalization default epsilon
 
@@ -29,8 +39,16 @@ def _stream():
   return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _require_gpu():
-  _lib.load()  # raises HipLibraryError when the extension is missing
+def precision_of(hp):
+  """'f16' under --mixed_precision (the reference's mixed_float16 policy,
+  main.py:22-30), else 'bf16'."""
+  return 'f16' if getattr(hp, 'mixed_precision', False) else 'bf16'
+
+
+def _require_gpu(hp=None):
+  # raises HipLibraryError when the extension is missing; every later launch of
+  # this process goes to the build this model computes with
+  _lib.use(precision_of(hp))
   if not torch.cuda.is_available():
     raise RuntimeError(
         'calciumgan_amd: no HIP device visible; the MI355X kernels are the only '
@@ -105,7 +123,7 @@ class PackedOperand(object):
     self.taps, self.Cx, self.CK, self.N = taps, Cx, CK, N_real
     self.nphase = len(phases)
     self.buf = torch.zeros(
-        self.nphase * self.elems, dtype=BF16, device=src.device)
+        self.nphase * self.elems, dtype=act_dtype(), device=src.device)
     self.src = src
     self.descs = []
     for i, (tap0, tap_step, s_tap, s_c, s_n) in enumerate(phases):
@@ -330,7 +348,7 @@ def _autotune_tile(d):
   # choice tuned for an unconstrained launch must not reach a constrained one)
   key = (d.stride, d.taps, d.nB, d.Lx, d.Cx, d.Lu, d.N, d.CK, d.nphase,
          d.epilogue, d.out_f32, d.w_narrow_last, int(bool(d.rowsumsq)),
-         int(bool(d.out_shifts)), int(bool(d.split_ws)))
+         int(bool(d.out_shifts)), int(bool(d.split_ws)), _precision_tag())
   from . import parallel
   multi = parallel.world_size() > 1
   best = _TILE_CACHE.get(key)
@@ -455,6 +473,8 @@ def _apply_tile_choice(d, best):
 _WGRAD_PARTIALS = __import__('os').environ.get('CALCIUMGAN_WGRAD_PARTIALS',
                                                 '1') != '0'
 _PARTIALS_POOL = {}
+# CALCIUMGAN_WGRAD_XCD=0: plain block order instead of the XCD-grouped one
+_WGRAD_XCD = __import__('os').environ.get('CALCIUMGAN_WGRAD_XCD', '1') != '0'
 
 
 def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,
@@ -471,6 +491,7 @@ def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,
   d.taps, d.stride, d.off = taps, stride, off
   d.Cx_real, d.Cg_real = Cx_real, Cg_real
   d.nsplit = 0
+  d.no_xcd_group = 0 if _WGRAD_XCD else 1
   if slot is not None and _WGRAD_PARTIALS and x.is_cuda:
     need = _lib.load().cg_wgrad_partials_elems(ctypes.byref(d))
     if need > 0:
@@ -542,7 +563,9 @@ class DiscriminatorNet(object):
   Dense(1)  (calciumgan.py:141-192)."""
 
   def __init__(self, hp, device, rng):
-    _require_gpu()
+    _require_gpu(hp)
+    self.precision = precision_of(hp)
+    self.h_dtype = act_dtype()  # torch dtype of activations / operands
     geo.validate_hparams(hp)
     self.hp = hp
     self.device = device
@@ -616,7 +639,7 @@ class _DisWorkspace(object):
     self.nB = nB
     L0 = net.layers[0].lin
     cp0 = net.layers[0].cinp
-    z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)
+    z = lambda *s, dt=None: torch.zeros(*s, dtype=dt or act_dtype(), device=dev)
     self.act = [z(nB, L0, cp0)] + [z(nB, l.lout, l.coutp) for l in net.layers]
     self.e = [None] + [z(nB, l.lout, l.coutp) for l in net.layers[:-1]]
     self.delta = [None] + [z(nB, l.lout, l.coutp) for l in net.layers]
@@ -676,7 +699,8 @@ class _DisPlan(object):
       fused = _FUSE_UNSHUFFLE and 2 * m + 1 <= lay.lin
       extra = {}
       if fused:
-        self.side[i] = torch.zeros(nB, m, lay.cinp, dtype=BF16, device=dev)
+        self.side[i] = torch.zeros(nB, m, lay.cinp, dtype=act_dtype(),
+                                   device=dev)
         extra = dict(mask_src=ws.act[i], epilogue=_lib.EPI_MASK,
                      out_shifts=(self.shifts[i - 1], seg_size, self.side[i], m))
       self.dgrad.append((i,
@@ -699,7 +723,8 @@ class _DisPlan(object):
       self.nG = nG
       # bf16 like every other activation gradient (its f32 sum of squares,
       # the penalty norm, is taken in the producing launch's epilogue)
-      self.gin = torch.zeros(nG, lay.lin, lay.cinp, dtype=BF16, device=dev)
+      self.gin = torch.zeros(nG, lay.lin, lay.cinp, dtype=act_dtype(),
+                             device=dev)
       # penalty norm fused into this launch's epilogue when a 256-row tile
       # never spans two samples; else the standalone cg_rownorm is used
       self.sumsq = None
@@ -799,7 +824,9 @@ class GeneratorNet(object):
   LayerNorm -> LeakyReLU] -> Dense(C) -> sigmoid  (calciumgan.py:22-103)."""
 
   def __init__(self, hp, device, rng):
-    _require_gpu()
+    _require_gpu(hp)
+    self.precision = precision_of(hp)
+    self.h_dtype = act_dtype()  # torch dtype of activations / operands
     self.w0 = geo.validate_hparams(hp)
     self.hp = hp
     self.device = device
@@ -892,7 +919,7 @@ class _GenWorkspace(object):
     dev = net.device
     self.net, self.B = net, B
     self.forward_only = forward_only
-    z = lambda *s, dt=BF16: torch.zeros(*s, dtype=dt, device=dev)
+    z = lambda *s, dt=None: torch.zeros(*s, dtype=dt or act_dtype(), device=dev)
     nd, w0 = net.nd, net.w0
     V = net.params.views
     self.z = z(B, 1, nd)
@@ -1044,6 +1071,31 @@ class _GenWorkspace(object):
 def adam_lr_t(step, lr, beta1=0.9, beta2=0.999):
   """Keras Adam's bias-corrected step size at 1-based iteration `step`."""
   return lr * math.sqrt(1.0 - beta2**step) / (1.0 - beta1**step)
+
+
+LOSS_SCALE_INIT = 2.0**15     # tf DynamicLossScale defaults (SURVEY A.8)
+LOSS_SCALE_INTERVAL = 2000
+
+
+def new_loss_scale_state(device):
+  """Device state of one dynamic loss scaler: [S, consecutive finite updates,
+  applied Adam steps, gradients-finite flag] (include/calciumgan_hip.h)."""
+  return torch.tensor([LOSS_SCALE_INIT, 0.0, 0.0, 1.0], dtype=torch.float32,
+                      device=device)
+
+
+def adam_update_scaled(params, lr, ls, grad_scale=1.0, beta1=0.9, beta2=0.999,
+                       eps=1e-7, interval=LOSS_SCALE_INTERVAL):
+  """LossScaleOptimizer(Adam).apply_gradients on gradients that carry the
+  loss scale ls[0] (optimizer.py:23-34): finite check, unscale + Keras Adam
+  (skipped when a gradient is inf / nan), then the scale's own update.  All on
+  the device: nothing here depends on a host-side step count."""
+  st = _stream()
+  _lib.call('cg_grad_finite', _p(params.grad), params.numel, _p(ls), st)
+  _lib.call('cg_adam_scaled', _p(params.data), _p(params.grad), _p(params.m),
+            _p(params.v), params.numel, lr, beta1, beta2, eps, grad_scale,
+            _p(ls), st)
+  _lib.call('cg_loss_scale_update', _p(ls), interval, st)
 
 
 def adam_update(params, step, lr, grad_scale=1.0, beta1=0.9, beta2=0.999,

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 9
+#define CG_ABI_VERSION 11
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -63,6 +63,16 @@ extern "C" {
 #define CG_NUM_TILES 14
 
 int cg_abi_version(void);
+/* Storage type of activations / activation gradients / packed operands this
+ * build of the library computes with (everything the comments below call
+ * "bf16"): libcalciumgan_hip.so is the bf16 build, libcalciumgan_hip_f16.so the
+ * IEEE fp16 build (-DCG_ACT_F16=1; the reference's mixed_float16 policy,
+ * main.py:22-30, with the loss scaling entry points at the end of this file).
+ * Accumulators, statistics, losses, master weights and Adam state are f32 in
+ * both. */
+#define CG_DTYPE_BF16 0
+#define CG_DTYPE_F16 1
+int cg_act_dtype(void);
 /* sizeof() of the descriptor structs as this library was compiled
  * (which: 0 cg_conv_desc, 1 cg_pack_desc, 2 cg_wgrad_desc; else -1): a binding
  * checks its own struct layout against it before the first launch. */
@@ -242,6 +252,7 @@ typedef struct cg_wgrad_desc {
   int Cx_real, Cg_real;
   int nsplit;        /* 0 = choose */
   int tile_rows;     /* 0 = choose; 64 or 128 rows of (b,u) per staged tile */
+  int no_xcd_group;  /* 1: plain block order instead of the XCD-grouped one (A/B runs) */
   float* dbias;      /* optional f32 [Cg_real]: += sum of g over its first
                         bias_rows (b,u) rows -- the conv bias gradient, taken
                         from the g tiles already staged in LDS */
@@ -374,6 +385,27 @@ int cg_adam(float* p, const float* grad, float* m, float* v, long long n,
             const float* lr_t_dev /* device scalar overriding lr_t, or NULL
                                      (lets a captured hipGraph vary the step) */,
             void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Dynamic loss scaling of the mixed_float16 mode -- mixed_precision.
+ * LossScaleOptimizer(Adam, 'dynamic') (gan/algorithms/optimizer.py:10-12,23-29):
+ * the loss is multiplied by S before the backward pass, the gradients divided by
+ * S before Adam; non-finite gradients skip the update and halve S (floor 1);
+ * `growth_interval` consecutive finite updates double it [TF: initial 2^15,
+ * interval 2000].  The state is four DEVICE floats, so a captured graph carries
+ * it without host round trips:
+ *   ls[0] = S, ls[1] = consecutive finite updates, ls[2] = applied Adam steps t,
+ *   ls[3] = 1 while the gradients of the update in progress look finite.
+ * One update = cg_grad_finite (clears ls[3] on any inf / nan; n % 4 == 0)
+ *           -> cg_adam_scaled (no-op when ls[3] == 0; g = grad*grad_scale/S;
+ *              lr_t from t = ls[2] + 1 as in cg_adam)
+ *           -> cg_loss_scale_update (advances S / counters, sets ls[3] = 1).
+ * ------------------------------------------------------------------------- */
+int cg_grad_finite(const float* grad, long long n, float* ls, void* stream);
+int cg_adam_scaled(float* p, const float* grad, float* m, float* v, long long n,
+                   float lr, float beta1, float beta2, float eps,
+                   float grad_scale, const float* ls, void* stream);
+int cg_loss_scale_update(float* ls, int growth_interval, void* stream);
 
 /* ---------------------------------------------------------------------------
  * GAN.metrics (gan/algorithms/gan.py:32-41, gan/utils/signals_metrics.py:9-28):

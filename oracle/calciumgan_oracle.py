@@ -31,6 +31,7 @@ __all__ = [
     'interpolation', 'gradient_penalty', 'discriminator_loss',
     'generator_loss', 'd_step_grads', 'g_step_grads', 'keras_adam',
     'signal_metrics', 'draw_randomness', 'OracleGAN', 'bf16_round',
+    'f16_round', 'DynamicLossScale',
     'LEAKY_ALPHA', 'LN_EPS', 'NUM_CONVS',
 ]
 
@@ -110,6 +111,55 @@ class _RoundBF16(torch.autograd.Function):
 
 def bf16_round(x):
   return _RoundBF16.apply(x)
+
+
+class _RoundF16(torch.autograd.Function):
+  """Straight-through IEEE fp16 rounding (mixed_float16 storage points; values
+  past 65504 become infinity, as the fp16 kernels store them)."""
+
+  @staticmethod
+  def forward(ctx, x):
+    return x.to(torch.float16).to(x.dtype)
+
+  @staticmethod
+  def backward(ctx, g):
+    return g
+
+
+def f16_round(x):
+  return _RoundF16.apply(x)
+
+
+class DynamicLossScale(object):
+  """tf.mixed_precision.experimental.DynamicLossScale as LossScaleOptimizer
+  drives it (gan/algorithms/optimizer.py:10-12,23-34) [ext, TF 2.3]: initial
+  scale 2**15; an update whose gradients are all finite is applied, and
+  `increment_period` (2000) consecutive ones double the scale; a non-finite
+  gradient skips the update (the inner optimizer's iteration count does not
+  advance), halves the scale (floor 1) and restarts the count."""
+
+  def __init__(self, initial=2.0**15, increment_period=2000, multiplier=2.0):
+    self.scale = float(initial)
+    self.period = int(increment_period)
+    self.multiplier = float(multiplier)
+    self.good_steps = 0
+
+  def update(self, grads):
+    """grads: the (unscaled) gradients of this update.  Returns True when the
+    update is to be applied."""
+    finite = all(bool(torch.isfinite(g).all()) for g in grads)
+    if finite:
+      if self.good_steps + 1 >= self.period:
+        new = self.scale * self.multiplier
+        if math.isfinite(new):
+          self.scale = new
+        self.good_steps = 0
+      else:
+        self.good_steps += 1
+    else:
+      self.scale = max(self.scale / self.multiplier, 1.0)
+      self.good_steps = 0
+    return finite
 
 
 def _ident(x):
@@ -442,7 +492,11 @@ class OracleGAN(object):
   reference object surface used by main.py (train / validate / generate)."""
 
   def __init__(self, hp, gen_weights, dis_weights, dtype=torch.float32,
-               emulate_bf16=False):
+               emulate_bf16=False, emulate_f16=False, loss_scaling=False):
+    """emulate_bf16 / emulate_f16: round stored activations and weight
+    operands like the bf16 / mixed_float16 kernels.  loss_scaling: wrap both
+    optimizers in DynamicLossScale (the backward here is f32, so the scale
+    itself changes nothing -- its skip / halve / grow state machine does)."""
     self.hp = hp
     self.dtype = dtype
     self.gen = [torch.tensor(np.asarray(w), dtype=dtype) for w in gen_weights]
@@ -453,8 +507,11 @@ class OracleGAN(object):
     self.dis_v = [torch.zeros_like(w) for w in self.dis]
     self.gen_steps = 0
     self.dis_steps = 0
-    self.q = bf16_round if emulate_bf16 else _ident
-    self.wq = bf16_round if emulate_bf16 else _ident
+    rnd = bf16_round if emulate_bf16 else f16_round if emulate_f16 else _ident
+    self.q = rnd
+    self.wq = rnd
+    self.gen_scale = DynamicLossScale() if loss_scaling else None
+    self.dis_scale = DynamicLossScale() if loss_scaling else None
 
   def _t(self, a):
     return torch.as_tensor(np.asarray(a), dtype=self.dtype)
@@ -463,6 +520,8 @@ class OracleGAN(object):
     res = d_step_grads(self.gen, self.dis, self._t(inputs), self._t(r['z']),
                        self._t(r['alpha']), r['shifts_real'], r['shifts_fake'],
                        r['shifts_inter'], self.hp, self.q, self.wq)
+    if self.dis_scale is not None and not self.dis_scale.update(res['grads']):
+      return res  # non-finite gradients: update skipped
     self.dis_steps += 1
     for p, g, m, v in zip(self.dis, res['grads'], self.dis_m, self.dis_v):
       keras_adam(p, g, m, v, self.dis_steps, self.hp.learning_rate)
@@ -471,9 +530,10 @@ class OracleGAN(object):
   def train_generator(self, inputs, r):
     res = g_step_grads(self.gen, self.dis, self._t(r['z']), r['shifts'],
                        self.hp, self.q, self.wq)
-    self.gen_steps += 1
-    for p, g, m, v in zip(self.gen, res['grads'], self.gen_m, self.gen_v):
-      keras_adam(p, g, m, v, self.gen_steps, self.hp.learning_rate)
+    if self.gen_scale is None or self.gen_scale.update(res['grads']):
+      self.gen_steps += 1
+      for p, g, m, v in zip(self.gen, res['grads'], self.gen_m, self.gen_v):
+        keras_adam(p, g, m, v, self.gen_steps, self.hp.learning_rate)
     res['metrics'] = signal_metrics(
         self._t(inputs), res['fake'], self.hp.signals_min, self.hp.signals_max,
         self.hp.normalize)

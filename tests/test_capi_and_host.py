@@ -88,10 +88,29 @@ def test_no_cpu_fallback_without_device():
 
 
 def test_missing_library_fails_loudly(monkeypatch):
-  monkeypatch.setattr(_lib, '_lib', None)
+  monkeypatch.setattr(_lib, '_libs', {})
   monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libcalciumgan_hip.so')
+  monkeypatch.setattr(_lib, 'LIB_PATH_F16', '/nonexistent/libcalciumgan_hip_f16.so')
   with pytest.raises(_lib.HipLibraryError):
     _lib.load()
+  with pytest.raises(_lib.HipLibraryError):
+    _lib.use('f16')
+  assert _lib.active() == 'bf16'
+
+
+def test_both_precision_builds_load_and_export_the_abi():
+  """libcalciumgan_hip.so (bf16 activations) and libcalciumgan_hip_f16.so
+  (-DCG_ACT_F16=1, mixed_float16) export every symbol of the header and say
+  which storage type they compute with."""
+  bf = _lib.load('bf16')
+  hf = _lib.load('f16')
+  assert bf.cg_act_dtype() == _lib.DTYPE_BF16
+  assert hf.cg_act_dtype() == _lib.DTYPE_F16
+  assert bf.cg_abi_version() == hf.cg_abi_version()
+  for name in _lib.SIGNATURES:
+    assert hasattr(hf, name) and hasattr(bf, name)
+  with pytest.raises(ValueError):
+    _lib.use('fp8')
 
 
 def test_registries_mirror_reference_contract(capsys):

@@ -68,7 +68,7 @@ def _flat(ts):
   ]).astype(np.float64)
 
 
-def _check_grads(got, emu, f32, what):
+def _check_grads(got, emu, f32, what, floor=1e-2):
   """got: HIP gradients; emu: oracle with the same bf16 storage points; f32:
   plain f32 oracle.
 
@@ -88,6 +88,10 @@ def _check_grads(got, emu, f32, what):
       cosine similarity >= 0.985;
     * tensors whose oracle gradient is exactly zero (dense bias of the critic)
       are zero.
+  `floor` is the additive term of the per-tensor bars (1e-2; the fp16 tests
+  pass 2e-2: the oracle's backward is f32, so its emu-f32 distance has no
+  share of the BACKWARD tensors' storage rounding, which in fp16 -- 11 bits but
+  a short exponent: small gradient entries go subnormal -- is the larger part).
   """
   bad = []
   for i, (g, e, r) in enumerate(zip(got, emu, f32)):
@@ -98,7 +102,7 @@ def _check_grads(got, emu, f32, what):
       assert np.abs(g).max() < 1e-6, '{} grad {} should be zero'.format(what, i)
       continue
     e_hf, e_ef, e_he = _rel(g, r), _rel(e, r), _rel(g, e)
-    if e_hf > 2.0 * e_ef + 1e-2 or e_he > 1.5 * e_ef + 1e-2:
+    if e_hf > 2.0 * e_ef + floor or e_he > 1.5 * e_ef + floor:
       bad.append((i, e_hf, e_ef, e_he))
   assert not bad, '{}: (idx, hip-f32, emu-f32, hip-emu) {}'.format(what, bad)
   gh, gr = _flat(got), _flat(f32)

@@ -221,3 +221,33 @@ def test_signal_metrics_known_answer():
   np.testing.assert_allclose(m['signals_metrics/max'].item(), (0 + 1) / 2)
   np.testing.assert_allclose(m['signals_metrics/mean'].item(), (1 + 0) / 2)
   np.testing.assert_allclose(m['signals_metrics/std'].item(), (1 + 1) / 2)
+
+
+def test_dynamic_loss_scale_state_machine():
+  """tf DynamicLossScale under LossScaleOptimizer (optimizer.py:10-12,23-34;
+  SURVEY A.8): initial 2**15, doubled after `increment_period` consecutive
+  finite updates, halved (floor 1) on a non-finite one, which is skipped."""
+  ls = O.DynamicLossScale()
+  assert ls.scale == 2.0**15 and ls.period == 2000
+  ok, bad = [torch.ones(3)], [torch.tensor([1.0, float('nan')])]
+  for _ in range(1999):
+    assert ls.update(ok)
+  assert ls.scale == 2.0**15 and ls.good_steps == 1999
+  assert ls.update(ok) and ls.scale == 2.0**16 and ls.good_steps == 0
+  assert not ls.update(bad) and ls.scale == 2.0**15 and ls.good_steps == 0
+  assert not ls.update([torch.tensor([float('inf')])]) and ls.scale == 2.0**14
+  ls.scale = 1.0
+  assert not ls.update(bad) and ls.scale == 1.0
+  # fp16 emulation: 11 significand bits, overflow to infinity past 65504
+  x = torch.tensor([1.0 + 2.0**-11, 65520.0, 1e-8])
+  r = O.f16_round(x)
+  assert float(r[0]) == 1.0 and torch.isinf(r[1]) and float(r[2]) == 0.0
+  # the scaler skips exactly the non-finite update of an oracle step
+  hp = O.make_hparams(64, 6, 8, m=2)
+  rng = np.random.RandomState(0)
+  gan = O.OracleGAN(hp, O.init_generator(hp, rng), O.init_discriminator(hp, rng),
+                    emulate_f16=True, loss_scaling=True)
+  real = rng.uniform(0, 1, (2, 64, 6)).astype(np.float32)
+  gan.train(real, O.draw_randomness(hp, 2, 0))
+  assert gan.dis_steps == hp.n_critic and gan.gen_steps == 1
+  assert gan.dis_scale.good_steps == hp.n_critic

@@ -4,7 +4,7 @@
   python tools/bench_conv.py conv  R taps nB Lx Cx N [CK] [small] [epi] [f32]
                                    [ksteps] [rowsumsq] [sp]
 (stride-2 operands are packed parity-major; sp = 1: split-parity staging)
-  python tools/bench_conv.py wgrad R taps nB Lx Cx Cg [nsplit]
+  python tools/bench_conv.py wgrad R taps nB Lx Cx Cg [nsplit] [tile_rows] [no_xcd_group]
 Lx is the source length; outputs Lu = Lx/2 (R=2) or Lx (R=1, 2 phases when
 taps > 1)."""
 import ctypes
@@ -86,15 +86,16 @@ def main():
     g = torch.randn(nB, Lu, Cg, device=dev).to(BF16)
     dw = torch.zeros(taps, Cx, Cg, device=dev)
     d = nets._wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, R,
-                         0 if taps == 1 else -(taps - 2) // 2, Cx, Cg)
+                         0 if taps == 1 else -(taps - 2) // 2, Cx, Cg, slot=0)
     d.nsplit = nsplit
     d.tile_rows = a[7] if len(a) > 7 else 0
+    d.no_xcd_group = a[8] if len(a) > 8 else 0
     st = nets._stream()
     t = timeit(lambda: _lib.call('cg_wgrad', ctypes.byref(d), st))
     fl = 2.0 * nB * Lu * Cg * taps * Cx
-    print('wgrad R%d taps%d nB%d Lu%d Cx%d Cg%d nsplit%d tile%d: %.1f us  %.1f TF/s'
-          % (R, taps, nB, Lu, Cx, Cg, nsplit, d.tile_rows, t * 1e6,
-             fl / t / 1e12))
+    print('wgrad R%d taps%d nB%d Lu%d Cx%d Cg%d nsplit%d tile%d plain%d: %.1f us  %.1f TF/s'
+          % (R, taps, nB, Lu, Cx, Cg, nsplit, d.tile_rows, d.no_xcd_group,
+             t * 1e6, fl / t / 1e12))
 
 
 if __name__ == '__main__':
