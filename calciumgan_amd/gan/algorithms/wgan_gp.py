@@ -123,7 +123,10 @@ class WGAN_GP(GAN):
     lay = net_d.layers[0]
     plan = st['critic']
     s = nets._stream()
-    plan.shifts.copy_(shifts, non_blocking=True)
+    # (host-drawn shifts of an eager step are a pageable temporary: a
+    # non-blocking copy could read it after it is gone once the host runs ahead
+    # of the GPU; the graph path hands a device view)
+    plan.shifts.copy_(shifts, non_blocking=shifts.is_cuda)
     self._scale_seeds(st, 'critic', self.dis_optimizer)
     if fake is None:
       fake = st['gws'].forward(z, keep=False)
@@ -245,7 +248,7 @@ class WGAN_GP(GAN):
     else:
       shifts = torch.as_tensor(r['shifts'], dtype=torch.int32).reshape(4, 1)
     s = nets._stream()
-    plan.shifts.copy_(shifts, non_blocking=True)
+    plan.shifts.copy_(shifts, non_blocking=shifts.is_cuda)
     self._scale_seeds(st, 'gen', self.gen_optimizer)
     _lib.call('cg_cast_pad', nets._p(fake), nets._p(st['dws'].act[0]),
               B * lay.lin, lay.cin, self.generator.net.Cf, lay.cinp, s)
@@ -497,11 +500,17 @@ class WGAN_GP(GAN):
     hipGraphs."""
     _lib.use(self.precision)
     real = self._to_device(inputs)
+    st = self._get_state(real.shape[0])
     if rand is None and self._use_graph:
-      st = self._get_state(real.shape[0])
       st['calls'] = st.get('calls', 0) + 1
       if st['calls'] > _GRAPH_WARMUP_CALLS:
         return self._train_graphed(real, st)
+    # an eager step between replays (injected randomness, main.py's --profile
+    # window): the captured graphs are dropped and re-captured at the next
+    # graphed call.  Measured: replaying the OLD graphs after eager steps gave
+    # garbage penalties in 6 of 14 processes (tools/dbg notes in DESIGN.md);
+    # freshly captured ones in 0 of 14
+    st.pop('graph', None)
     return self._train_body(real, rand)
 
   def validate(self, inputs, rand=None):

@@ -156,6 +156,13 @@ def parse_example(data):
 # ---------------------------------------------------------------------------
 # TFRecord framing
 # ---------------------------------------------------------------------------
+def frame(record):
+  """One framed TFRecord: length | masked crc(length) | data | masked crc(data)."""
+  header = struct.pack('<Q', len(record))
+  return (header + struct.pack('<I', masked_crc32c(header)) + bytes(record) +
+          struct.pack('<I', masked_crc32c(record)))
+
+
 class TFRecordWriter(object):
   """tf.io.TFRecordWriter counterpart (generate_tfrecords.py:150-153)."""
 
@@ -163,11 +170,7 @@ class TFRecordWriter(object):
     self._f = open(path, 'wb')
 
   def write(self, record):
-    header = struct.pack('<Q', len(record))
-    self._f.write(header)
-    self._f.write(struct.pack('<I', masked_crc32c(header)))
-    self._f.write(record)
-    self._f.write(struct.pack('<I', masked_crc32c(record)))
+    self._f.write(frame(record))
 
   def close(self):
     self._f.close()

@@ -8,11 +8,13 @@ of bryanlimy/CalciumGAN), driving the MI355X hot path.
       --layer_norm --mixed_precision
   torchrun --nproc-per-node 8 main.py ...        (data parallel over RCCL)
 
-Differences, all documented: compute is bf16 MFMA with f32 accumulation on
-every run (--mixed_precision is accepted; there is no fp16 loss scaling);
-scalars go to JSONL instead of TensorBoard; trace plots / spike deconvolution
-in the loop (main.py:142-154) are out of scope; under torchrun every rank
-trains on its own shard of each batch and rank 0 writes the files.
+Differences, all documented: without --mixed_precision activations are bf16
+(f32 accumulation, f32 master weights) where the reference computes in f32;
+with it they are fp16 with the reference's dynamic loss scaling
+(mixed_float16).  Scalars go to TensorBoard event files (written without
+TensorFlow) and JSON lines; trace plots / spike deconvolution in the loop
+(main.py:142-154) are out of scope; under torchrun every rank trains on its
+own shard of each batch and rank 0 writes the files.
 """
 import argparse
 import os
@@ -27,12 +29,20 @@ np.random.seed(1234)  # main.py:11
 def train(hparams, train_ds, gan, summary, epoch):
   """main.py:33-75."""
   gen_losses, dis_losses, gradient_penalties = [], [], []
+  batch_count = 0
   start = time()
   for signal, _ in train_ds:
     signal = _shard(hparams, signal)
     if signal is None:  # ragged last batch smaller than the world size
       continue
+    # --profile: batches 2..6 of the second epoch (main.py:45-52)
+    profiling = hparams.profile and epoch == 1 and summary is not None
+    if profiling and batch_count == 2:
+      summary.profiler_trace(gan)
     gen_loss, dis_loss, gradient_penalty, metrics = gan.train(signal)
+    if profiling and batch_count == 6:
+      summary.profiler_export()
+    batch_count += 1
     gen_losses.append(gen_loss)
     dis_losses.append(dis_loss)
     if gradient_penalty is not None:
@@ -213,8 +223,8 @@ def build_parser():
   parser.add_argument('--skip_checkpoints', action='store_true')
   parser.add_argument('--mixed_precision', action='store_true')
   parser.add_argument('--profile', action='store_true',
-                      help='accepted for compatibility: profile by running '
-                      'the command under rocprofv3 --kernel-trace --stats')
+                      help='time every MFMA-kernel launch of batches 2-6 of the '
+                      'second epoch -> <output_dir>/profiler/mfma_kernels.json')
   parser.add_argument('--dpi', default=120, type=int)
   parser.add_argument('--verbose', default=1, type=int)
   return parser

@@ -1,12 +1,15 @@
 """CPU tests of the compatibility layer around the hot path (SURVEY 8(f)
 rows 3-4, Appendix C): CLI flag surface, hparams.json, checkpoint pickle
 layout + resume, generated-sample store, scalar tags, dataset directory."""
+import glob
 import json
 import os
 import pickle
+import struct
 from types import SimpleNamespace
 
 import numpy as np
+import pytest
 
 import main as cli
 from calciumgan_amd.data import dg
@@ -275,3 +278,44 @@ def test_write_dataset_as_tfrecord_shards(tmp_path):
     np.testing.assert_array_equal(out[0][k].signals, out[1][k].signals)
     np.testing.assert_array_equal(out[0][k].spikes.astype(np.float32),
                                   out[1][k].spikes)
+
+
+def test_tensorboard_event_files(tmp_path):
+  """Summary.scalar writes TensorBoard event files (TFRecord framing + Event /
+  Summary protobufs, tb_events.py) next to the JSON lines: first record the
+  file version, then one scalar event per call with the reference's tags and
+  steps; every record's CRCs verify."""
+  from calciumgan_amd.gan.utils import tb_events
+  hp = SimpleNamespace(output_dir=str(tmp_path / 'run'), verbose=0)
+  os.makedirs(hp.output_dir)
+  s = Summary(hp)
+  s.log(1.5, -2.25, 0.125, metrics={'signals_metrics/min': 3.0}, elapse=7.0,
+        step=4, training=True)
+  s.scalar('loss/generator', 9.0, step=2, training=False)
+  tr = glob.glob(os.path.join(hp.output_dir, 'events.out.tfevents.*'))
+  va = glob.glob(os.path.join(hp.output_dir, 'validation',
+                              'events.out.tfevents.*'))
+  assert len(tr) == 1 and len(va) == 1
+  ev = tb_events.read_events(tr[0])
+  assert ev[0]['file_version'] == b'brain.Event:2'
+  got = [(e['tag'], e['value'], e['step']) for e in ev[1:]]
+  assert got == [('loss/generator', 1.5, 4), ('loss/discriminator', -2.25, 4),
+                 ('loss/gradient_penalty', 0.125, 4),
+                 ('signals_metrics/min', 3.0, 4), ('elapse', 7.0, 4)]
+  assert all(e['wall_time'] > 1.6e9 for e in ev)
+  ev = tb_events.read_events(va[0])
+  assert (ev[1]['tag'], ev[1]['value'], ev[1]['step']) == ('loss/generator',
+                                                           9.0, 2)
+  # hand-assembled known answer of the wire format: Event{wall_time=1.0,
+  # step=3, summary{value{tag="a", simple_value=0.5}}}
+  want = (b'\x09' + struct.pack('<d', 1.0) + b'\x10\x03' +
+          b'\x2a\x0a' + b'\x0a\x08' + b'\x0a\x01a' + b'\x15' +
+          struct.pack('<f', 0.5))
+  assert tb_events.encode_event(1.0, 3, 'a', 0.5) == want
+  # a flipped payload byte is caught by the record CRC
+  raw = bytearray(open(tr[0], 'rb').read())
+  raw[-6] ^= 0xff
+  bad = tmp_path / 'bad.tfevents'
+  bad.write_bytes(bytes(raw))
+  with pytest.raises(IOError):
+    tb_events.read_events(str(bad))

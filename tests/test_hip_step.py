@@ -407,16 +407,20 @@ def test_graph_replay_matches_eager():
     assert d / np.linalg.norm(outs[False][i]) < 1e-3
 
 
-def test_outputs_stay_valid_across_graph_replays():
+@pytest.mark.parametrize('use_graph', [True, False])
+def test_outputs_stay_valid_across_graph_replays(use_graph):
   """main.py keeps the tensors train() returns in lists and converts them at
   the END of an epoch (reference main.py:34-40).  With the step replayed as a
   hipGraph the launches rewrite the same device buffers every step, so train()
   must hand out copies: outputs kept without any host sync equal the values
   read step by step, and the host-drawn staging inputs (phase shifts, Adam
-  step sizes) of step N are not overwritten by the host running ahead."""
+  step sizes) of step N are not overwritten by the host running ahead.
+  use_graph = False: the same for eager launches (main.py's --profile window),
+  whose host-drawn phase shifts are pageable temporaries."""
   runs = {}
   for keep in (False, True):
     hp, gen, dis, gan, real, B = _build('tiny')
+    gan._use_graph = use_graph
     held, now = [], []
     for step in range(8):
       o = gan.train(real)
@@ -429,7 +433,7 @@ def test_outputs_stay_valid_across_graph_replays():
     if keep:
       now = [[float(o[0]), float(o[1]), float(o[2])] +
              [float(o[3][k]) for k in sorted(o[3])] for o in held]
-    assert gan._get_state(B).get('graph') is not None
+    assert (gan._get_state(B).get('graph') is not None) == use_graph
     runs[keep] = (np.array(now), _flat(dis.get_weights()),
                   _flat(gen.get_weights()))
   # the same steps, read immediately or at the end: not "the last step 8 times"

@@ -1,0 +1,116 @@
+"""The host loop of main.py on the GPU (reference main.py:125-224): two tiny
+epochs of train -> validate -> generated samples -> checkpoint, the --profile
+window, a resume from the checkpoint, and the same under --mixed_precision."""
+import glob
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+import main as cli
+from calciumgan_amd.data import dg
+from calciumgan_amd.gan.utils import dataset_helper, h5_helper, tb_events
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _back_to_bf16():
+  yield
+  from calciumgan_amd import _lib
+  _lib.use('bf16')
+
+
+def _dataset(tmp_path, n=70, L=256, C=16):
+  d = dg.make_dataset(num_neurons=C, sequence_length=L, num_segments=n)
+  info = {k: v for k, v in d['info'].items() if k != 'rates_hz'}
+  path = str(tmp_path / 'ds')
+  dataset_helper.write_dataset(path, d['signals'], d['spikes'], info,
+                               validation_size=6)
+  return path
+
+
+def _args(input_dir, output_dir, *extra):
+  a = cli.build_parser().parse_args([
+      '--input_dir', input_dir, '--output_dir', output_dir, '--model',
+      'calciumgan', '--algorithm', 'wgan-gp', '--batch_size', '8', '--num_units',
+      '8', '--m', '2', '--layer_norm', '--epochs', '2', '--save_generated',
+      'last', '--verbose', '0'] + list(extra))
+  a.global_step = 0
+  a.surrogate_ds = False
+  return a
+
+
+def _scalars(path):
+  return [json.loads(l) for l in open(path)]
+
+
+def test_main_trains_validates_saves_and_resumes(tmp_path):
+  ds = _dataset(tmp_path)
+  out = str(tmp_path / 'run')
+  hp = _args(ds, out, '--profile')
+  metrics = cli.main(hp, return_metrics=True)
+  assert set(metrics) == {'signals_metrics/min', 'signals_metrics/max',
+                          'signals_metrics/mean', 'signals_metrics/std'}
+  assert all(np.isfinite(v) for v in metrics.values()), metrics
+  # 64 training segments / batch 8 = 8 train() per epoch (each kept as a device
+  # scalar until the end of the epoch: the graph-replay aliasing regression)
+  assert hp.global_step == 16
+  tr = _scalars(os.path.join(out, 'scalars.jsonl'))
+  tags = [r['tag'] for r in tr if r['step'] == 1]
+  assert {'loss/generator', 'loss/discriminator', 'loss/gradient_penalty',
+          'elapse', 'samples_per_sec'} <= set(tags)
+  assert all(np.isfinite(r['value']) for r in tr)
+  va = _scalars(os.path.join(out, 'validation', 'scalars.jsonl'))
+  assert {'loss/generator', 'signals_metrics/std'} <= {r['tag'] for r in va}
+  # TensorBoard event files beside them
+  ev = glob.glob(os.path.join(out, 'events.out.tfevents.*'))
+  assert len(ev) == 1
+  assert len(tb_events.read_events(ev[0])) == len(tr) + 1
+  # checkpoints of epochs 0 and 1, Keras weight order
+  ck = sorted(glob.glob(os.path.join(out, 'checkpoints', 'epoch-*.pkl')))
+  assert [os.path.basename(c) for c in ck] == ['epoch-000.pkl', 'epoch-001.pkl']
+  c1 = pickle.load(open(ck[1], 'rb'))
+  assert c1['epoch'] == 1 and len(c1['gen_weights']) == 24
+  assert len(c1['dis_weights']) == 12
+  assert int(c1['dis_steps']) == 80 and int(c1['gen_steps']) == 16
+  # generated samples of the last epoch: the 6 validation segments, denormalised
+  gen = h5_helper.get(os.path.join(out, 'generated', 'epoch001_signals.h5'),
+                      'signals')
+  assert gen.shape == (6, 256, 16) and np.isfinite(gen).all()
+  val = h5_helper.get(os.path.join(out, 'generated', 'validation.h5'), 'signals')
+  assert val.shape == (6, 256, 16)
+  # --profile: batches 2..6 of the second epoch, every MFMA launch timed
+  prof = json.load(open(os.path.join(out, 'profiler', 'mfma_kernels.json')))
+  fam = prof['families']
+  assert fam['cg_swconv']['launches'] > 100 and fam['cg_wgrad']['launches'] > 20
+  assert fam['cg_swconv']['mean_us'] > 0
+  # resume: two more epochs continue from epoch 2 with the optimizers' counts
+  hp2 = _args(ds, out, '--epochs', '3')
+  hp2.epochs = 3
+  cli.main(hp2)
+  ck = sorted(glob.glob(os.path.join(out, 'checkpoints', 'epoch-*.pkl')))
+  assert os.path.basename(ck[-1]) == 'epoch-002.pkl'
+  c2 = pickle.load(open(ck[-1], 'rb'))
+  assert int(c2['dis_steps']) == 120 and int(c2['gen_steps']) == 24
+  moved = sum(float(np.abs(a - b).sum())
+              for a, b in zip(c1['gen_weights'], c2['gen_weights']))
+  assert moved > 0
+
+
+def test_main_mixed_precision_runs_fp16_with_loss_scaling(tmp_path):
+  ds = _dataset(tmp_path)
+  out = str(tmp_path / 'run16')
+  hp = _args(ds, out, '--mixed_precision', '--epochs', '1')
+  hp.epochs = 1
+  cli.main(hp)
+  tr = _scalars(os.path.join(out, 'scalars.jsonl'))
+  scale = [r['value'] for r in tr if r['tag'] == 'model/loss_scale']
+  assert scale and 1.0 <= scale[-1] <= 2.0**15
+  assert all(np.isfinite(r['value']) for r in tr)
+  ck = pickle.load(open(os.path.join(out, 'checkpoints', 'epoch-000.pkl'), 'rb'))
+  # applied steps: at most 8 train() x (5 + 1) updates, fewer if the scaler
+  # had to skip overflowing ones on its way down from 2**15
+  assert 0 < int(ck['dis_steps']) <= 40 and 0 < int(ck['gen_steps']) <= 8
