@@ -41,6 +41,9 @@ _FORCE_SPLIT = os.environ.get('CALCIUMGAN_SPLIT_SEGMENTS', '0') == '1'
 # of a step (CALCIUMGAN_BATCH_G=0: one pass per update, as under data
 # parallelism, where each pass hides the previous update's all-reduce)
 _BATCH_G = os.environ.get('CALCIUMGAN_BATCH_G', '1') != '0'
+# data parallel, A/B only: wait for every gradient all-reduce right after it is
+# started instead of overlapping it with the next segment
+_DP_OVERLAP = os.environ.get('CALCIUMGAN_DP_OVERLAP', '1') != '0'
 _METRIC_KEYS = ('signals_metrics/min', 'signals_metrics/max',
                 'signals_metrics/mean', 'signals_metrics/std')
 # pinned staging slots for the host-drawn inputs of a graph replay: the host may
@@ -374,6 +377,9 @@ class WGAN_GP(GAN):
       launch(fn)
       if grad is not None:
         pending = self._sync.all_reduce_async(grad)
+        if not _DP_OVERLAP and pending is not None:
+          pending.wait()
+          pending = None
     if pending is not None:
       pending.wait()
 

@@ -27,9 +27,10 @@ def _free_port():
   return p
 
 
-def test_two_rank_train_keeps_replicas_identical(tmp_path):
+def _run_workers(tmp_path, backend):
   env = dict(os.environ)
   env['DP_WORKER_OUT'] = str(tmp_path)
+  env['DP_BACKEND'] = backend
   env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
          '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
@@ -42,8 +43,27 @@ def test_two_rank_train_keeps_replicas_identical(tmp_path):
           for r in (0, 1)]
   assert sorted(r['rank'] for r in recs) == [0, 1]
   for r in recs:
-    assert r['world'] == 2
+    assert r['world'] == 2 and r['backend'] == backend
     assert r['weights_identical'], r
     assert r['finite'], r
     assert r['graphed'] and r['segments'] == 2 * 5 + 3, r
     assert r['noise_differs'], r
+    # losses / metrics are all-reduced once per step: every rank logs the
+    # global mean; rank 0's tuned tiles are broadcast: identical launches
+    assert r['logged_identical'], r
+    assert r['tiles_identical'], r
+
+
+def test_two_rank_train_keeps_replicas_identical(tmp_path):
+  _run_workers(tmp_path, 'gloo')
+
+
+def test_two_rank_train_over_rccl(tmp_path):
+  """The same two ranks over backend 'nccl' (= RCCL), one GPU each: runs
+  wherever the box has at least two devices (the driver's 8-GPU node), skipped
+  on the single-GPU test box."""
+  import torch
+  if torch.cuda.device_count() < 2:
+    pytest.skip('needs one GPU per rank (found {})'.format(
+        torch.cuda.device_count()))
+  _run_workers(tmp_path, 'nccl')
