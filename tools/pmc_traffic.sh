@@ -16,7 +16,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     for f in glob.glob('gpurun_out/traffic_%s/*/*counter_collection.csv' % c):
         for r in csv.DictReader(open(f)):
             n = r['Kernel_Name']
-            fam = ('swconv' if 'swconv_kernel' in n else
+            fam = ('swconv' if ('swconv_kernel' in n or 'swconv_swp_kernel' in n) else
                    'wgrad_reduce' if 'wgrad_reduce' in n else
                    'wgrad' if 'wgrad_' in n else None)
             if fam is None or r['Counter_Name'] != c:
@@ -36,7 +36,7 @@ for fam, d in res.items():
                     hbm_bytes_per_launch=(2 * fetch_kb + write_kb) * 1024)
 import subprocess
 try:
-    out['commit'] = open('gpurun_out/HEAD_COMMIT').read().strip()
+    out['commit'] = open('profiles/.head_commit').read().strip()
 except OSError:
     out['commit'] = None
 print(json.dumps(out, indent=1))

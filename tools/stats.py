@@ -8,8 +8,12 @@ rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("launch set: %s  (divided by %g recorded train() steps: warm-up + timed + the eager instrumented pass)" % (f.split('/')[-1], steps))
 print("total kernel ms/step %.2f" % (tot / 1e6 / steps))
-for fam in ("swconv_kernel", "wgrad"):  # wgrad_kernel + wgrad_multi_kernel
-    sel = [r for r in rows if fam in r["Name"]]
+# swconv: the tile kernels (swconv_kernel), the software-pipelined tiles
+# (swconv_swp_kernel) and the split-K finishing launches ride in one family, as
+# bench.py times them; wgrad: wgrad_kernel + wgrad_multi_kernel + the reduce
+for fam, pats in (("swconv", ("swconv_kernel", "swconv_swp_kernel")),
+                  ("wgrad", ("wgrad",))):
+    sel = [r for r in rows if any(p in r["Name"] for p in pats)]
     calls = sum(int(r["Calls"]) for r in sel)
     ns = sum(float(r["TotalDurationNs"]) for r in sel)
     print("FAMILY %-14s %6d calls (%.1f per step) %8.1f us avg %6.2f ms/step %5.1f%%" % (
