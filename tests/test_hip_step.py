@@ -161,7 +161,7 @@ def _term_grads(hp, gen, dis, real, r, term, q):
   return torch.autograd.grad(loss, dw, allow_unused=True)
 
 
-@pytest.mark.parametrize('name', ['tiny', 'mid', 'odd_c'])
+@pytest.mark.parametrize('name', ['tiny', 'mid', 'odd_c', 'long', 'c40'])
 @pytest.mark.parametrize('term', ['real', 'fake', 'gp'])
 def test_critic_loss_terms_separately(name, term):
   """Gradient of ONE term of the critic loss (wgan_gp.py:58-61) at a time (the
