@@ -28,7 +28,7 @@ import torch.distributed as dist
 MFMA_BF16_PEAK = 2.5e15  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def make_hparams(L, C, U, m):
+def make_hparams(L, C, U, m, mixed_precision=False):
   from types import SimpleNamespace
   return SimpleNamespace(
       signal_shape=(L, C), sequence_length=L, num_channels=C, num_neurons=C,
@@ -36,7 +36,8 @@ def make_hparams(L, C, U, m):
       m=m, layer_norm=True, batch_norm=False, normalize=True,
       activation='leakyrelu', gradient_penalty=10.0, n_critic=5,
       learning_rate=1e-4, signals_min=0.0, signals_max=1.0, conv2d=False,
-      mixed_precision=False, model='calciumgan', algorithm='wgan-gp', verbose=0)
+      mixed_precision=bool(mixed_precision), model='calciumgan',
+      algorithm='wgan-gp', verbose=0)
 
 
 def algorithmic_flops(hp):
@@ -170,6 +171,9 @@ def main():
   ap.add_argument('--neurons', type=int, default=102)
   ap.add_argument('--num_units', type=int, default=64)
   ap.add_argument('--m', type=int, default=10)
+  ap.add_argument('--mixed_precision', action='store_true',
+                  help='fp16 activations + dynamic loss scaling (the '
+                  "reference's mixed_float16; BASELINE.json configs[4])")
   ap.add_argument('--no_cpu_baseline', action='store_true')
   ap.add_argument('--cpu_batch', type=int, default=8)
   ap.add_argument('--cpu_steps', type=int, default=3)
@@ -194,7 +198,8 @@ def main():
   from calciumgan_amd.gan.algorithms import get_algorithm
   from calciumgan_amd.gan.models import get_models
 
-  hp = make_hparams(args.seq_len, args.neurons, args.num_units, args.m)
+  hp = make_hparams(args.seq_len, args.neurons, args.num_units, args.m,
+                    args.mixed_precision)
   gen, dis = get_models(hp, None)
   gan = get_algorithm(hp, gen, dis, None)
 
@@ -257,11 +262,15 @@ def main():
 
   # the workload label follows the arguments: only BASELINE.json configs[1]
   # shapes are called cfg2
-  default_workload = (args.seq_len, args.neurons, args.num_units, args.m,
-                      B) == (2048, 102, 64, 10, 128)
+  default_workload = (args.seq_len, args.neurons, args.num_units, args.m, B,
+                      args.mixed_precision) == (2048, 102, 64, 10, 128, False)
   cfg_name = 'cfg2' if default_workload else (
       'cfg1 shapes' if (args.seq_len, args.neurons) == (256, 16) else
+      'cfg5' if (args.seq_len, args.neurons, B, args.mixed_precision) ==
+      (8192, 512, 256, True) else
       'cfg5 shapes' if (args.seq_len, args.neurons) == (8192, 512) else
+      'cfg2 shapes, mixed_float16' if (args.seq_len, args.neurons, args.num_units,
+                                       args.m, B) == (2048, 102, 64, 10, 128) else
       'custom shapes (not a BASELINE.json config)')
   if rank == 0:
     fl = algorithmic_flops(hp)
@@ -324,7 +333,7 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'bf16',
+        'dtype': 'f16' if args.mixed_precision else 'bf16',
         'data': 'synthetic',
         'config': {
             'workload': '{}: dichotomised-Gaussian sl{} calcium signals, {} '
