@@ -31,6 +31,7 @@
 //     (after the barrier that publishes stage s+1 and frees slot s) the DMA of
 //     stage s+3 is issued into slot s; it has two whole stages to land.
 #include <type_traits>
+#include <utility>
 
 #include "swconv_args.h"
 
@@ -58,13 +59,7 @@ struct SwpArgs {
 
 constexpr int kSwpScrPitch = 68;  // f32 epilogue scratch pitch
 constexpr int kSwpRing = 3;       // weight ring depth
-// fragment reads spread one per two MFMAs by sched_group_barrier (measured
-// slower than hipcc's own "all reads, then the MFMAs" order on 9 of 12 cfg2
-// geometries, up to +35 % on the first critic layer; kept for A/B runs)
-#ifndef CG_SWP_INTERLEAVE
-#define CG_SWP_INTERLEAVE 0
-#endif
-constexpr bool kSwpInterleave = CG_SWP_INTERLEAVE != 0;
+constexpr int kSwpTapsPerPass = 12;  // 24-tap stride-2 / 12-tap stride-1 windows
 
 __device__ __forceinline__ int sw64(int byte) {
   // XOR-swizzle of a byte offset into a window of 64-byte rows: row bit 2
@@ -72,14 +67,38 @@ __device__ __forceinline__ int sw64(int byte) {
   return byte ^ ((byte >> 3) & 32);
 }
 
-// A compiler-visible use of fragments that were read a whole MFMA block ago:
-// hipcc places its s_waitcnt lgkmcnt HERE (nothing newer is in flight: precise
-// and free) instead of in front of their first MFMA, which by then sits behind
-// the next K-step's freshly issued reads (lgkmcnt(0) there stalls on those).
-template <int N>
-__device__ __forceinline__ void landed(const act8 (&f)[N]) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) asm volatile("" ::"v"(f[i]));
+// compile-time loop: f(integral_constant<int, 0>), ..., f(integral_constant<int, N - 1>)
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>,
+                                                F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// The K loop's LDS reads and MFMAs are inline assembly: hipcc, given the
+// builtins and the unrolled pass, renames every accumulator per K-step and
+// copies it back (562 v_mov, 90-170 spilled VGPRs); `+v` ties the MFMA's
+// destination to its accumulator, the reads land in fixed fragment sets, and
+// volatile asm keeps the stream in program order.  The compiler does not see
+// these reads, so the waits are placed by hand (s_waitcnt lgkmcnt(0) after the
+// MFMA block that hid their latency).
+template <int OFF>
+__device__ __forceinline__ void lds_read128(act8& d, int addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void mfma_acc(f32x4& c, const act8& a, const act8& b) {
+#if CG_ACT_F16
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#else
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#endif
+}
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // R: source stride.  WM x WN waves (4 or 8); wave tile (16 * MT) x 64.
@@ -98,10 +117,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
   static_assert(NBW >= 1, "at least one weight piece per wave and stage");
   // window pieces per wave (windows of at most TM + 8 * 11 rows: nseg <= 8)
   constexpr int KPW = (TM / 16 + 6 + NW - 1) / NW;
+  // one pass = TPP taps = NST 64-deep weight stages, fully unrolled below: tap
+  // and ring-slot numbers are compile-time, so every fragment read is a
+  // per-lane base register + an immediate offset (no address arithmetic in the
+  // loop).  The window buffers have a compile-time stride for the same reason.
+  constexpr int TPP = kSwpTapsPerPass;
+  constexpr int NST = TPP / KS;
+  static_assert(NST % kSwpRing == 0, "the ring slot of a stage is compile-time");
+  constexpr int ABYTES = KPW * NW * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsA = smem;
-  uint16_t* ldsB = reinterpret_cast<uint16_t*>(smem + 2 * pa.abytes);
-  int* sh_lds = reinterpret_cast<int*>(smem + 2 * pa.abytes + kSwpRing * kBufB * 2);
+  uint16_t* ldsB = reinterpret_cast<uint16_t*>(smem + 2 * ABYTES);
+  int* sh_lds = reinterpret_cast<int*>(smem + 2 * ABYTES + kSwpRing * kBufB * 2);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -197,9 +224,20 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
         o == ~0u ? pa.zero : xbytes + ((unsigned long long)o << 4) + add;
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)src,
-        (__attribute__((address_space(3))) void*)(ldsA + (p & 1) * pa.abytes +
+        (__attribute__((address_space(3))) void*)(ldsA + (p & 1) * ABYTES +
                                                   (k * NW + wave) * 1024),
         16, 0, 0);
+  };
+  // piece slot K (compile-time) of pass p; returns 1 if this wave owns it
+  auto issue_a_slot = [&](int p, auto k_tag) {
+    constexpr int K = decltype(k_tag)::value;
+    if constexpr (K < KPW) {
+      if ((K * NW + wave) < pa.npa) {
+        issue_a_piece(p, K, aoff[K][0], aoff[K][R - 1], aq[K]);
+        return 1;
+      }
+    }
+    return 0;
   };
   // pieces k in [k0, k1) of pass p; returns how many were issued
   auto issue_a_range = [&](int p, int k0, int k1) {
@@ -226,22 +264,24 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
     if (row >= pa.npad_rows) row = pa.npad_rows - 1;  // columns past N: unused
     dsrc[i] = wp + (long long)row * a.Kpack + c * 8;
   }
-  auto issue_b = [&](int gs) {
-    uint16_t* slot = ldsB + (gs % kSwpRing) * kBufB;
+  // (running source pointers: + one 64-deep stage per issue)
+  auto issue_b = [&](int slot_idx) {
+    uint16_t* slot = ldsB + slot_idx * kBufB;
 #pragma unroll
-    for (int i = 0; i < NBW; ++i)
+    for (int i = 0; i < NBW; ++i) {
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(dsrc[i] +
-                                                          (long long)gs * (KS * 32)),
+          (const __attribute__((address_space(1))) void*)dsrc[i],
           (__attribute__((address_space(3))) void*)(slot + (wave * NBW + i) * 512),
           16, 0, 0);
+      dsrc[i] += KS * 32;
+    }
   };
 
   // ---- fragment addresses ----------------------------------------------------
-  // window byte offset of (first tile row of this lane, k-group g), tap 0,
-  // unswizzled.  A wave's 16 MT rows lie in ONE segment (S >= 16 MT, checked on
-  // the host), so subtile mt is +mt KiB: the swizzle (bit 5 from bit 8) is
-  // computed once per tap and the subtiles are immediate offsets
+  // A: window byte offset of (first tile row of this lane, k-group g) at tap t,
+  // swizzled, one register per tap of a pass.  A wave's 16 MT rows lie in ONE
+  // segment (S >= 16 MT, checked on the host), so subtile mt is +mt KiB and the
+  // other window buffer +ABYTES: immediates (the swizzle moves bit 5 by bit 8)
   int rowb0;
   {
     const int i = wm * MT * 16 + rM;
@@ -249,41 +289,41 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
     const int ui = i & (a.S - 1);
     rowb0 = (seg * pa.WRs + ui) * 64 + g * 16;
   }
+  // (absolute LDS byte addresses: the reads are inline assembly)
+  const int lds0 = (int)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  int aaddr[TPP];
+#pragma unroll
+  for (int t = 0; t < TPP; ++t) aaddr[t] = lds0 + sw64(rowb0 + t * 64);
+  // narrow chunk: stage s -> parity s >> 1, K-step (s & 1) * 2 + ks; its four
+  // k-groups are four consecutive taps of that parity over the same 8 channels
+  // (chunk slot = parity); taps past taps/2 carry zero weights (row clamped: LDS
+  // may hold anything finite)
+  const int half_taps = a.taps >> 1;
+  auto naddr = [&](int s, int ks, int buf_off) {
+    int idx = 4 * ((s & 1) * 2 + ks) + g;
+    idx = idx < half_taps ? idx : half_taps - 1;
+    return lds0 + buf_off + sw64(rowb0 - g * 16 + idx * 64 + (s >> 1) * 16);
+  };
+  // B: byte offset of this lane's fragment row in ring slot 0 per K-step
   const int swzB = (rM >> 1) & 7;
-  int boff[KS];
+  int vboff[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
-    boff[ks] = (wn * 64 + rM) * kRowB + (((4 * ks + g) ^ swzB) * 8);
-  const int half_taps = a.taps >> 1;
-
-  // fragments of K-step ks of stage s (global index gs) of pass p
-  auto read_frags = [&](act8(&af)[MT], act8(&bf)[NT], int p, int s, int gs,
-                        int ks) {
-    const uint16_t* curB = ldsB + (gs % kSwpRing) * kBufB;
-    const unsigned char* abuf = ldsA + (p & 1) * pa.abytes;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      bf[nt] = *reinterpret_cast<const act8*>(curB + nt * 16 * kRowB +
-                                                (ks ? boff[1] : boff[0]));
-    if (p < full_passes) {
-      const int tapoff = (s * KS + ks) * 64;  // one tap per K-step
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        af[mt] = *reinterpret_cast<const act8*>(
-            abuf + sw64(rowb0 + mt * 1024 + tapoff));
-    } else {
-      // narrow chunk: stage s -> parity s >> 1, K-step (s & 1) * 2 + ks; its
-      // four k-groups are four consecutive taps of that parity over the same 8
-      // channels (chunk slot = parity); taps past taps/2 carry zero weights
-      // (row clamped: LDS may hold anything finite)
-      const int par = s >> 1;
-      int idx = 4 * ((s & 1) * 2 + ks) + g;
-      idx = idx < half_taps ? idx : half_taps - 1;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        af[mt] = *reinterpret_cast<const act8*>(
-            abuf + sw64(rowb0 + mt * 1024 - g * 16 + idx * 64 + par * 16));
-    }
+    vboff[ks] = lds0 + 2 * ABYTES +
+                ((wn * 64 + rM) * kRowB + (((4 * ks + g) ^ swzB) * 8)) * 2;
+  // (slot, K-step, subtile and buffer are template arguments: immediates)
+  auto read_b = [&](act8(&bf)[NT], auto slot_tag, auto ks_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    constexpr int KSI = decltype(ks_tag)::value;
+    static_for<NT>([&](auto nt) {
+      lds_read128<SLOT * (kBufB * 2) + decltype(nt)::value * 16 * kRowB * 2>(
+          bf[decltype(nt)::value], vboff[KSI]);
+    });
+  };
+  auto read_a = [&](act8(&af)[MT], int addr) {
+    static_for<MT>([&](auto mt) {
+      lds_read128<decltype(mt)::value * 1024>(af[decltype(mt)::value], addr);
+    });
   };
 
   f32x4 acc[MT][NT];
@@ -295,23 +335,25 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] = cg_mfma_16x16x32(af[mt], bf[nt],
-                                                              acc[mt][nt], 0, 0, 0);
+      for (int nt = 0; nt < NT; ++nt) mfma_acc(acc[mt][nt], af[mt], bf[nt]);
   };
-
-  // scheduling pattern of a half stage: the MT + NT fragment reads of the next
-  // K-step go out one per two MFMAs of the current one (a burst of reads in
-  // front of a burst of MFMAs leaves the LDS pipe and the matrix pipe taking
-  // turns; both waves of a SIMD reach their bursts together after a barrier)
-  auto interleave = [&]() {
-    if (!kSwpInterleave) return;
-#pragma unroll
-    for (int i = 0; i < MT + NT; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one DS read
-      __builtin_amdgcn_sched_group_barrier(0x008, (MT * NT) / (MT + NT), 0);
+  // counted wait at a stage boundary: all but this wave's newest DMAs (weight
+  // stage gs + 2 if it exists, the previous stage's `na` window pieces) done
+  auto wait_stage = [&](bool later_b, int na) {
+    if (na == 0) {
+      if (later_b) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (na == 1) {
+      if (later_b) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else {
+      if (later_b) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW + 2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     }
   };
+  using std::integral_constant;
+  using I0 = integral_constant<int, 0>;
+  using I1 = integral_constant<int, 1>;
 
   // ---- prologue: window of pass 0, weight stages 0..2, first fragments --------
   issue_a_range(0, 0, KPW);
@@ -321,66 +363,76 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   act8 af0[MT], bf0[NT], af1[MT], bf1[NT];
-  read_frags(af0, bf0, 0, 0, 0, 0);
-  landed(af0);
-  landed(bf0);
+  read_b(bf0, I0{}, I0{});
+  read_a(af0, full_passes > 0 ? aaddr[0] : naddr(0, 0, 0));
+  lds_wait();
 
+  // One pass, NSTG stages unrolled.  aaddr[] points into the window buffer of
+  // the current pass (the buffers alternate: +-ABYTES on every tap address at
+  // the end of a pass -- one body instead of one per buffer).
+  // Per stage: [reads of K-step 1 | MFMAs of K-step 0] counted wait + barrier
+  // (publishes stage gs + 1, frees slot gs and the other window buffer)
+  // [reads of the next stage's K-step 0 | DMA issue | MFMAs of K-step 1].
   int gs = 0;
-  int na_prev = 0;  // window pieces this wave issued in the previous stage
-  for (int p = 0; p < pa.npass; ++p) {
-    const int nst_p = p >= full_passes ? 4 : pa.nst;
-    for (int s = 0; s < nst_p; ++s, ++gs) {
-      // ---- first half: K-step 1 is read while K-step 0 multiplies -----------
-      read_frags(af1, bf1, p, s, gs, 1);
-      if (!kSwpInterleave) __builtin_amdgcn_sched_barrier(0);
+  auto run_pass = [&](auto narrow_tag, int p) {
+    constexpr bool NARROW = decltype(narrow_tag)::value;
+    constexpr int NSTG = NARROW ? 4 : NST;
+    const bool next_narrow = p + 1 >= full_passes;  // (the pass after, if any)
+    const bool has_next = p + 1 < pa.npass;
+    const int cur_off = (p & 1) * ABYTES;
+    const int delta = (p & 1) ? -ABYTES : ABYTES;
+    int na_prev = 0;
+    static_for<NSTG>([&](auto s_tag) {
+      constexpr int s = decltype(s_tag)::value;
+      using SLOT = integral_constant<int, s % kSwpRing>;
+      using SLOT1 = integral_constant<int, (s + 1) % kSwpRing>;
+      // ---- first half -------------------------------------------------------
+      read_b(bf1, SLOT{}, I1{});
+      read_a(af1, NARROW ? naddr(s, 1, cur_off) : aaddr[(s * KS + 1) % TPP]);
       mfma_step(af0, bf0);
-      interleave();
-      __builtin_amdgcn_sched_barrier(0);
-      landed(af1);
-      landed(bf1);
-      // ---- stage boundary ----------------------------------------------------
-      // weight stage gs + 1 (issued two stages ago) and every window piece but
-      // those of the previous stage have landed once all but this wave's newest
-      // (stage gs + 2, previous stage's window pieces) DMAs are done; the
-      // barrier publishes them and frees slot gs / the other window buffer
-      {
-        const int nb = gs + 2 < pa.total_stages ? NBW : 0;
-        if (na_prev == 0) {
-          if (nb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW) : "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (na_prev == 1) {
-          if (nb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW + 1) : "memory");
-          else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        } else {
-          if (nb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW + 2) : "memory");
-          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        }
-      }
+      lds_wait();
+      // ---- stage boundary ---------------------------------------------------
+      wait_stage(gs + 2 < pa.total_stages, na_prev);
       __builtin_amdgcn_s_barrier();
-      // ---- second half: K-step 0 of the next stage is read while K-step 1
-      // multiplies
-      if (gs + 1 < pa.total_stages) {
-        const bool last_of_pass = s + 1 == nst_p;
-        read_frags(af0, bf0, last_of_pass ? p + 1 : p, last_of_pass ? 0 : s + 1,
-                   gs + 1, 0);
+      // ---- second half ------------------------------------------------------
+      if constexpr (s + 1 < NSTG) {
+        read_b(bf0, SLOT1{}, I0{});
+        read_a(af0, NARROW ? naddr(s + 1, 0, cur_off) : aaddr[((s + 1) * KS) % TPP]);
+      } else {
+        // first K-step of the next pass (other window buffer, ring slot 0);
+        // after the last pass a harmless read of resident LDS
+        read_b(bf0, I0{}, I0{});
+        read_a(af0, next_narrow ? naddr(0, 0, cur_off + delta) : aaddr[0] + delta);
       }
-      __builtin_amdgcn_sched_barrier(0);
       // (the DMA issue sits behind the reads: in front of them the LDS pipe and
       // the matrix pipe both idle while the wave builds addresses)
-      if (gs + 3 < pa.total_stages) issue_b(gs + 3);
-      // window of the next pass: issued in stages 0 .. nst - 3 of this pass, so
-      // the wait of stage nst - 1 (which leaves only the previous stage's
-      // pieces in flight) retires all of them before the first read
+      if (gs + 3 < pa.total_stages) issue_b(s % kSwpRing);
+      // window of the next pass: stages 0 .. NSTG - 3 of this pass, so the wait
+      // of stage NSTG - 1 (which leaves only the previous stage's pieces in
+      // flight) retires all of them before the first read
       na_prev = 0;
-      if (p + 1 < pa.npass && s <= nst_p - 3)
-        na_prev = issue_a_range(p + 1, s * pa.apw, (s + 1) * pa.apw);
+      if constexpr (!NARROW && s <= NSTG - 3) {
+        if (has_next) {
+          // apw (1 or 2) slots of this wave per issuing stage
+          if (pa.apw == 1) {
+            na_prev = issue_a_slot(p + 1, integral_constant<int, s>{});
+          } else {
+            na_prev = issue_a_slot(p + 1, integral_constant<int, 2 * s>{}) +
+                      issue_a_slot(p + 1, integral_constant<int, 2 * s + 1>{});
+          }
+        }
+      }
       mfma_step(af1, bf1);
-      interleave();
-      __builtin_amdgcn_sched_barrier(0);
-      landed(af0);
-      landed(bf0);
-    }
-  }
+      lds_wait();
+      ++gs;
+    });
+#pragma unroll
+    for (int t = 0; t < TPP; ++t) aaddr[t] += delta;
+  };
+  for (int p = 0; p < full_passes; ++p) run_pass(integral_constant<bool, false>{}, p);
+  if (a.narrow) run_pass(integral_constant<bool, true>{}, full_passes);
+  // (the epilogue reads the accumulators with ordinary instructions: the
+  // matrix pipe drains behind the barrier + LDS round trip in front of them)
 
   // ---- epilogue: accumulators -> LDS -> whole-line row-contiguous stores ------
   // (the non-LayerNorm epilogue of swconv_kernel; 16x16 accumulators)
@@ -540,7 +592,7 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   pa.tpp = a.taps / stride;
   // whole 64-deep stages per pass, and stages 0 .. nst - 3 to issue the next
   // window in
-  if (pa.tpp % 2 || pa.tpp / 2 < 3) return CG_EINVAL;
+  if (pa.tpp != kSwpTapsPerPass) return CG_EINVAL;  // the pass loop is unrolled
   pa.nst = pa.tpp / 2;
   pa.WRs = a.S + pa.tpp - 1;
   pa.wrows = a.nseg * pa.WRs;
@@ -557,7 +609,11 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   pa.total_stages = (a.nchunks - narrow) * stride * pa.nst + narrow * 4;
   pa.npad_rows = (a.N + 127) / 128 * 128;
   pa.inv_WRs = 1.0f / (float)pa.WRs;
-  size_t lds = (size_t)2 * pa.abytes + (size_t)kSwpRing * tn * 64 * 2 + 128;
+  // (window buffers at the tile's compile-time stride: KPW pieces per wave)
+  const int tm = wm * mt * 16;
+  const int kpw_max = (tm / 16 + 6 + nw - 1) / nw;
+  if (kpw > kpw_max) return CG_EINVAL;
+  size_t lds = (size_t)2 * kpw_max * nw * 1024 + (size_t)kSwpRing * tn * 64 * 2 + 128;
   const size_t epi = (size_t)nw * 16 * kSwpScrPitch * 4 + 64;
   if (lds < epi) lds = epi;
   if (lds > 160 * 1024) return CG_EINVAL;
@@ -570,7 +626,6 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   CG_SWP_R(4, 1, 4)   // 256 x 64, 4 waves
   CG_SWP_R(4, 2, 4)   // 256 x 128, 8 waves
   CG_SWP_R(2, 2, 4)   // 128 x 128, 4 waves
-  CG_SWP_R(2, 4, 4)   // 128 x 256, 8 waves
 #undef CG_SWP_R
 #undef CG_SWP
   return CG_EINVAL;

@@ -59,8 +59,7 @@ extern "C" {
 #define CG_TILE_SWP_256x64 10
 #define CG_TILE_SWP_256x128 11
 #define CG_TILE_SWP_128x128 12
-#define CG_TILE_SWP_128x256 13
-#define CG_NUM_TILES 14
+#define CG_NUM_TILES 13
 
 int cg_abi_version(void);
 /* Storage type of activations / activation gradients / packed operands this
