@@ -102,9 +102,11 @@ __device__ __forceinline__ void lds_wait() {
 }
 
 // R: source stride.  WM x WN waves (4 or 8); wave tile (16 * MT) x 64.
-template <int R, int WM, int WN, int MT>
+// LN: CG_EPI_LN_LRELU (LayerNorm + LeakyReLU in the epilogue; 128-column tiles).
+template <int R, int WM, int WN, int MT, bool LN = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) {
   static_assert(WM * WN == 4 || WM * WN == 8, "one or two waves per SIMD");
+  static_assert(!LN || WN == 2, "the fused LayerNorm needs a 128-column tile");
   const ConvArgs& a = pa.c;
   constexpr int NW = WM * WN;
   constexpr int NT = 4;
@@ -177,12 +179,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
   // (kept as 32-bit offsets from x in 16-byte units, ~0 = zero page: half the
   // registers of 64-bit pointers, and nothing for the compiler to hoist)
   uint32_t aoff[KPW][R];
-  int aq[KPW];          // logical 16-byte chunk this lane fetches
+  // logical 16-byte chunk this lane fetches: pieces start at multiples of 16
+  // rows, so row bit 2 is lane bit 4 for every piece
+  const int aq = pslot ^ (((lane >> 4) & 1) << 1);
 #pragma unroll
   for (int k = 0; k < KPW; ++k) {
     const int row = (k * NW + wave) * 16 + (lane >> 2);
-    const int q = pslot ^ (((row >> 2) & 1) << 1);
-    aq[k] = q;
+    const int q = aq;
     int seg = 0;
     if (a.nseg > 1) seg = __float2int_rz(((float)row + 0.5f) * pa.inv_WRs);
     const int wr = row - seg * pa.WRs;
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
     constexpr int K = decltype(k_tag)::value;
     if constexpr (K < KPW) {
       if ((K * NW + wave) < pa.npa) {
-        issue_a_piece(p, K, aoff[K][0], aoff[K][R - 1], aq[K]);
+        issue_a_piece(p, K, aoff[K][0], aoff[K][R - 1], aq);
         return 1;
       }
     }
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
 #pragma unroll
     for (int k = 0; k < KPW; ++k)
       if (k >= k0 && k < k1 && (k * NW + wave) < pa.npa) {
-        issue_a_piece(p, k, aoff[k][0], aoff[k][R - 1], aq[k]);
+        issue_a_piece(p, k, aoff[k][0], aoff[k][R - 1], aq);
         ++n;
       }
     return n;
@@ -373,12 +376,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
   // Per stage: [reads of K-step 1 | MFMAs of K-step 0] counted wait + barrier
   // (publishes stage gs + 1, frees slot gs and the other window buffer)
   // [reads of the next stage's K-step 0 | DMA issue | MFMAs of K-step 1].
-  int gs = 0;
   auto run_pass = [&](auto narrow_tag, int p) {
     constexpr bool NARROW = decltype(narrow_tag)::value;
+    // only in the final pass of the tile can a later weight stage be missing
+    // (every other pass is followed by at least 4 stages)
+    const bool last = p + 1 == pa.npass;
     constexpr int NSTG = NARROW ? 4 : NST;
     const bool next_narrow = p + 1 >= full_passes;  // (the pass after, if any)
-    const bool has_next = p + 1 < pa.npass;
     const int cur_off = (p & 1) * ABYTES;
     const int delta = (p & 1) ? -ABYTES : ABYTES;
     int na_prev = 0;
@@ -392,7 +396,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
       mfma_step(af0, bf0);
       lds_wait();
       // ---- stage boundary ---------------------------------------------------
-      wait_stage(gs + 2 < pa.total_stages, na_prev);
+      // (window pieces are only issued in stages 0 .. NSTG - 3: none can be in
+      // flight at the boundaries of stage 0 and of the last stage)
+      if constexpr (s == 0 || s == NSTG - 1 || NARROW)
+        wait_stage(!last || s + 2 < NSTG, 0);
+      else
+        wait_stage(!last || s + 2 < NSTG, na_prev);
       __builtin_amdgcn_s_barrier();
       // ---- second half ------------------------------------------------------
       if constexpr (s + 1 < NSTG) {
@@ -406,13 +415,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
       }
       // (the DMA issue sits behind the reads: in front of them the LDS pipe and
       // the matrix pipe both idle while the wave builds addresses)
-      if (gs + 3 < pa.total_stages) issue_b(s % kSwpRing);
+      if (!last || s + 3 < NSTG) issue_b(s % kSwpRing);
       // window of the next pass: stages 0 .. NSTG - 3 of this pass, so the wait
       // of stage NSTG - 1 (which leaves only the previous stage's pieces in
       // flight) retires all of them before the first read
       na_prev = 0;
       if constexpr (!NARROW && s <= NSTG - 3) {
-        if (has_next) {
+        if (!last) {
           // apw (1 or 2) slots of this wave per issuing stage
           if (pa.apw == 1) {
             na_prev = issue_a_slot(p + 1, integral_constant<int, s>{});
@@ -424,23 +433,35 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
       }
       mfma_step(af1, bf1);
       lds_wait();
-      ++gs;
     });
 #pragma unroll
     for (int t = 0; t < TPP; ++t) aaddr[t] += delta;
   };
-  for (int p = 0; p < full_passes; ++p) run_pass(integral_constant<bool, false>{}, p);
-  if (a.narrow) run_pass(integral_constant<bool, true>{}, full_passes);
+  using False = integral_constant<bool, false>;
+  using True = integral_constant<bool, true>;
+  for (int p = 0; p < full_passes; ++p) run_pass(False{}, p);
+  if (a.narrow) run_pass(True{}, full_passes);
   // (the epilogue reads the accumulators with ordinary instructions: the
   // matrix pipe drains behind the barrier + LDS round trip in front of them)
 
   // ---- epilogue: accumulators -> LDS -> whole-line row-contiguous stores ------
-  // (the non-LayerNorm epilogue of swconv_kernel; 16x16 accumulators)
+  // (the epilogues of swconv_kernel on 16x16 accumulators)
   __syncthreads();
   float* scr = reinterpret_cast<float*>(smem) + wave * (16 * kSwpScrPitch);
+  // fused LayerNorm + LeakyReLU: the row statistics span the two waves that
+  // share a row block (wave ^ 1); their partial sums meet in a small LDS table
+  // behind the transpose scratch, gamma / beta sit next to it
+  float* part = reinterpret_cast<float*>(smem) + NW * 16 * kSwpScrPitch;
+  float* lnp = part + NW * 16 * 2;  // gamma[128] | beta[128] (zero past N)
+  if constexpr (LN) {
+    if (tid < 128) {
+      lnp[tid] = tid < a.N ? a.ln_gamma[tid] : 0.f;
+      lnp[128 + tid] = tid < a.N ? a.ln_beta[tid] : 0.f;
+    }
+  }
   const int erow = lane >> 3;
   const int cg8 = lane & 7;
-  const bool of32 = a.out_f32;
+  const bool of32 = !LN && a.out_f32;  // (the LayerNorm form stores bf16)
   const int colA = of32 ? cg8 * 4 : cg8 * 8;
   const int colB = of32 ? colA + 32 : colA + 4;
   const int nA = n0 + wn * 64 + colA;
@@ -466,7 +487,73 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
     for (int pass = 0; pass < 2; ++pass) {
       const int row = pass * 8 + erow;
       const int m = m0 + (wm * MT + mt) * 16 + row;
-      if (m < a.M && nA < a.Cy) {
+      if constexpr (LN) {
+        // (every lane takes part: the workgroup barrier below is uniform)
+        const f32x4 v0 =
+            *reinterpret_cast<const f32x4*>(scr + row * kSwpScrPitch + colA);
+        const f32x4 v1 =
+            *reinterpret_cast<const f32x4*>(scr + row * kSwpScrPitch + colB);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int n = (e < 4 ? nA : nB - 4) + e;
+          // statistics of the STORED pre-activation, as the separate
+          // cg_ln_lrelu_fwd pass sees it
+          v[e] = n < a.N ? act2f(f2act(v[e] + bv[e])) : 0.f;
+          s1 += v[e];
+          s2 += v[e] * v[e];
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+          s1 += __shfl_xor(s1, o, 64);
+          s2 += __shfl_xor(s2, o, 64);
+        }
+        if (cg8 == 0)
+          *reinterpret_cast<float2*>(part + (wave * 16 + row) * 2) =
+              make_float2(s1, s2);
+        __syncthreads();
+        const float2 o2 =
+            *reinterpret_cast<const float2*>(part + ((wave ^ 1) * 16 + row) * 2);
+        const float invn = 1.f / (float)a.N;
+        const float mean = (s1 + o2.x) * invn;
+        const float var = fmaxf((s2 + o2.y) * invn - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + a.ln_eps);
+        if (m < a.M && nA < a.Cy) {
+          const int b = m / a.Lu;
+          const int u = m - b * a.Lu;
+          const long long ridx =
+              (long long)b * a.Ly + (long long)a.y_stride * u + y_off;
+          const long long rowoff = ridx * a.Cy;
+          const int lc = wn * 64 + colA;
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(lnp + lc);
+          const f32x4 g1 = *reinterpret_cast<const f32x4*>(lnp + lc + 4);
+          const f32x4 b0v = *reinterpret_cast<const f32x4*>(lnp + 128 + lc);
+          const f32x4 b1v = *reinterpret_cast<const f32x4*>(lnp + 128 + lc + 4);
+          float hv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float t = (v[e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) +
+                            (e < 4 ? b0v[e] : b1v[e - 4]);
+            hv[e] = fmaxf(t, a.alpha * t);
+          }
+          // (forward-only callers pass no statistics buffers: the
+          // pre-activation is then not stored either)
+          if (a.ln_mean)
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.y) + rowoff +
+                                      nA) =
+                make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]),
+                           pack2act(v[4], v[5]), pack2act(v[6], v[7]));
+          *reinterpret_cast<uint4*>(a.ln_h + rowoff + nA) =
+              make_uint4(pack2act(hv[0], hv[1]), pack2act(hv[2], hv[3]),
+                         pack2act(hv[4], hv[5]), pack2act(hv[6], hv[7]));
+          if (a.ln_mean && wn == 0 && cg8 == 0) {
+            a.ln_mean[ridx] = mean;
+            a.ln_rstd[ridx] = rstd;
+          }
+        }
+      }
+      if (!LN && m < a.M && nA < a.Cy) {
         const int b = m / a.Lu;
         const int u = m - b * a.Lu;
         int t = a.y_stride * u + y_off;
@@ -554,18 +641,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
   }
 }
 
-template <int R, int WM, int WN, int MT>
+template <int R, int WM, int WN, int MT, bool LN = false>
 int launch_swp(const SwpArgs& pa, dim3 grid, size_t lds, bool dry, hipStream_t s) {
   if (dry) return 0;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&swconv_swp_kernel<R, WM, WN, MT>),
+        reinterpret_cast<const void*>(&swconv_swp_kernel<R, WM, WN, MT, LN>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  CG_LAUNCH_PROF(CG_FAMILY_SWCONV, (swconv_swp_kernel<R, WM, WN, MT>), grid,
+  CG_LAUNCH_PROF(CG_FAMILY_SWCONV, (swconv_swp_kernel<R, WM, WN, MT, LN>), grid,
                  dim3(WM * WN * 64), lds, s, pa);
   CG_LAUNCH_CHECK();
 }
@@ -574,11 +661,11 @@ int launch_swp(const SwpArgs& pa, dim3 grid, size_t lds, bool dry, hipStream_t s
 
 int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
                       int ksplit, bool dry, hipStream_t stream) {
-  // uniform 32-channel K walk, one tap per K-step; no LayerNorm epilogue, no
-  // split-K (the tile kernels keep those)
-  if (a.CK != 32 || a.taps % stride || ksplit > 1 ||
-      a.epilogue == CG_EPI_LN_LRELU)
-    return CG_EINVAL;
+  // uniform 32-channel K walk, one tap per K-step; no split-K (the tile
+  // kernels keep that); the fused LayerNorm needs whole rows in the workgroup
+  if (a.CK != 32 || a.taps % stride || ksplit > 1) return CG_EINVAL;
+  const bool ln = a.epilogue == CG_EPI_LN_LRELU;
+  if (ln && (wn != 2 || stride != 1 || a.N > 128)) return CG_EINVAL;
   if (stride == 2 && !a.pmajor) return CG_EINVAL;
   const int nw = wm * wn, tn = wn * 64;
   static const void* zero_page = nullptr;
@@ -614,10 +701,16 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   const int kpw_max = (tm / 16 + 6 + nw - 1) / nw;
   if (kpw > kpw_max) return CG_EINVAL;
   size_t lds = (size_t)2 * kpw_max * nw * 1024 + (size_t)kSwpRing * tn * 64 * 2 + 128;
-  const size_t epi = (size_t)nw * 16 * kSwpScrPitch * 4 + 64;
+  // transpose scratch + rowsumsq slots / LayerNorm tables behind it
+  const size_t epi = (size_t)nw * 16 * kSwpScrPitch * 4 + nw * 16 * 2 * 4 + 256 * 4 + 64;
   if (lds < epi) lds = epi;
   if (lds > 160 * 1024) return CG_EINVAL;
   dim3 grid((unsigned)(((a.gm + 7) / 8) * 8 * a.gn * a.gp));
+  if (ln) {
+    if (wm == 4 && mt == 4) return launch_swp<1, 4, 2, 4, true>(pa, grid, lds, dry, stream);
+    if (wm == 2 && mt == 4) return launch_swp<1, 2, 2, 4, true>(pa, grid, lds, dry, stream);
+    return CG_EINVAL;
+  }
 #define CG_SWP(RR, WM, WN, MM)                                  \
   if (stride == RR && wm == WM && wn == WN && mt == MM)         \
     return launch_swp<RR, WM, WN, MM>(pa, grid, lds, dry, stream);

@@ -385,7 +385,7 @@ def _autotune_tile(d):
         cands.append(small)
     cands = [(small, ks, 0, 1) for small in cands for ks in (2, 4)]
     swp = []
-    if (_SWP_TILES and d.CK == 32 and d.epilogue != _lib.EPI_LN_LRELU and
+    if (_SWP_TILES and d.CK == 32 and
         d.taps % d.stride == 0 and (d.taps // d.stride) % 2 == 0 and
         d.taps // d.stride >= 6 and (d.stride == 1 or d.w_parity_major)):
       # software-pipelined tiles (two waves per SIMD, swconv_swp.hip)
@@ -393,7 +393,10 @@ def _autotune_tile(d):
         ok = (d.Lu % tm == 0) if d.Lu >= tm else (tm % d.Lu == 0)
         if d.rowsumsq and d.Lu < tm:
           ok = False
-        if tn > 64 and d.N <= (tn // 2 if tn > 128 else 64):
+        if d.epilogue == _lib.EPI_LN_LRELU:
+          if tn != 128:
+            ok = False
+        elif tn > 64 and d.N <= 64:
           ok = False
         if ok:
           swp.append((small, 2, 0, 1))

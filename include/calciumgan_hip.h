@@ -53,8 +53,8 @@ extern "C" {
  * workgroup or two 4-wave workgroups per CU), fragments double-buffered in
  * registers at K-step granularity, the source window and the weight ring both
  * filled by LDS-DMA.  v_mfma_f32_16x16x32, CK == 32, at least six taps per
- * source-row parity; no LayerNorm epilogue, no split-K.  Same results as the
- * tiles above. */
+ * source-row parity; no split-K; the LayerNorm epilogue on the 128-column tiles.
+ * Same results as the tiles above. */
 #define CG_TILE_SWP_512x64 9
 #define CG_TILE_SWP_256x64 10
 #define CG_TILE_SWP_256x128 11
