@@ -88,6 +88,7 @@ class WgradDesc(C.Structure):
       ('nsplit', c_i),
       ('tile_rows', c_i),
       ('no_xcd_group', c_i),
+      ('classic_staging', c_i),
       ('dbias', c_vp),
       ('bias_rows', c_ll),
       ('partials', c_vp),

@@ -4,6 +4,9 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "../../include/calciumgan_hip.h"
 
 // Storage type of activations / activation gradients / packed MFMA operands:
@@ -104,3 +107,38 @@ __device__ __forceinline__ float wave_min(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// compile-time loop: f(integral_constant<int, 0>), ..., f(integral_constant<int, N - 1>)
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>,
+                                                F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// The K loop's LDS reads and MFMAs are inline assembly: hipcc, given the
+// builtins and the unrolled pass, renames every accumulator per K-step and
+// copies it back (562 v_mov, 90-170 spilled VGPRs); `+v` ties the MFMA's
+// destination to its accumulator, the reads land in fixed fragment sets, and
+// volatile asm keeps the stream in program order.  The compiler does not see
+// these reads, so the waits are placed by hand (s_waitcnt lgkmcnt(0) after the
+// MFMA block that hid their latency).
+template <int OFF>
+__device__ __forceinline__ void lds_read128(act8& d, int addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void mfma_acc(f32x4& c, const act8& a, const act8& b) {
+#if CG_ACT_F16
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#else
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#endif
+}
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+

@@ -30,9 +30,6 @@
 //   * weight ring: 3 slots of 64-deep stages.  In the second half of stage s
 //     (after the barrier that publishes stage s+1 and frees slot s) the DMA of
 //     stage s+3 is issued into slot s; it has two whole stages to land.
-#include <type_traits>
-#include <utility>
-
 #include "swconv_args.h"
 
 namespace {
@@ -67,40 +64,6 @@ __device__ __forceinline__ int sw64(int byte) {
   return byte ^ ((byte >> 3) & 32);
 }
 
-// compile-time loop: f(integral_constant<int, 0>), ..., f(integral_constant<int, N - 1>)
-template <int... I, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>,
-                                                F&& f) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-
-// The K loop's LDS reads and MFMAs are inline assembly: hipcc, given the
-// builtins and the unrolled pass, renames every accumulator per K-step and
-// copies it back (562 v_mov, 90-170 spilled VGPRs); `+v` ties the MFMA's
-// destination to its accumulator, the reads land in fixed fragment sets, and
-// volatile asm keeps the stream in program order.  The compiler does not see
-// these reads, so the waits are placed by hand (s_waitcnt lgkmcnt(0) after the
-// MFMA block that hid their latency).
-template <int OFF>
-__device__ __forceinline__ void lds_read128(act8& d, int addr) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-__device__ __forceinline__ void mfma_acc(f32x4& c, const act8& a, const act8& b) {
-#if CG_ACT_F16
-  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-#else
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-#endif
-}
-__device__ __forceinline__ void lds_wait() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
 // R: source stride.  WM x WN waves (4 or 8); wave tile (16 * MT) x 64.
 // LN: CG_EPI_LN_LRELU (LayerNorm + LeakyReLU in the epilogue; 128-column tiles).
 template <int R, int WM, int WN, int MT, bool LN = false>
@@ -126,7 +89,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
   constexpr int TPP = kSwpTapsPerPass;
   constexpr int NST = TPP / KS;
   static_assert(NST % kSwpRing == 0, "the ring slot of a stage is compile-time");
-  constexpr int ABYTES = KPW * NW * 1024;
+  // (windows of at most TM + 8 * 11 rows = TM / 16 + 6 pieces: nseg <= 8)
+  constexpr int ABYTES = (TM / 16 + 6) * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsA = smem;
   uint16_t* ldsB = reinterpret_cast<uint16_t*>(smem + 2 * ABYTES);
@@ -659,6 +623,14 @@ int launch_swp(const SwpArgs& pa, dim3 grid, size_t lds, bool dry, hipStream_t s
 
 }  // namespace
 
+const unsigned char* cg_zero_page() {
+  static const void* zp = nullptr;
+  if (!zp && hipGetSymbolAddress(const_cast<void**>(&zp), HIP_SYMBOL(g_zero_page)) !=
+                 hipSuccess)
+    zp = nullptr;
+  return reinterpret_cast<const unsigned char*>(zp);
+}
+
 int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
                       int ksplit, bool dry, hipStream_t stream) {
   // uniform 32-channel K walk, one tap per K-step; no split-K (the tile
@@ -668,14 +640,11 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   if (ln && (wn != 2 || stride != 1 || a.N > 128)) return CG_EINVAL;
   if (stride == 2 && !a.pmajor) return CG_EINVAL;
   const int nw = wm * wn, tn = wn * 64;
-  static const void* zero_page = nullptr;
-  if (!zero_page &&
-      hipGetSymbolAddress(const_cast<void**>(&zero_page), HIP_SYMBOL(g_zero_page)) !=
-          hipSuccess)
-    return CG_EINVAL;
+  const unsigned char* zero_page = cg_zero_page();
+  if (!zero_page) return CG_EINVAL;
   SwpArgs pa;
   pa.c = a;
-  pa.zero = reinterpret_cast<const unsigned char*>(zero_page);
+  pa.zero = zero_page;
   pa.tpp = a.taps / stride;
   // whole 64-deep stages per pass, and stages 0 .. nst - 3 to issue the next
   // window in
@@ -698,9 +667,9 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   pa.inv_WRs = 1.0f / (float)pa.WRs;
   // (window buffers at the tile's compile-time stride: KPW pieces per wave)
   const int tm = wm * mt * 16;
-  const int kpw_max = (tm / 16 + 6 + nw - 1) / nw;
-  if (kpw > kpw_max) return CG_EINVAL;
-  size_t lds = (size_t)2 * kpw_max * nw * 1024 + (size_t)kSwpRing * tn * 64 * 2 + 128;
+  const int npa_max = tm / 16 + 6;
+  if (pa.npa > npa_max) return CG_EINVAL;
+  size_t lds = (size_t)2 * npa_max * 1024 + (size_t)kSwpRing * tn * 64 * 2 + 128;
   // transpose scratch + rowsumsq slots / LayerNorm tables behind it
   const size_t epi = (size_t)nw * 16 * kSwpScrPitch * 4 + nw * 16 * 2 * 4 + 256 * 4 + 64;
   if (lds < epi) lds = epi;

@@ -45,6 +45,8 @@ struct WgradArgs {
   // block, split) [they share x]; 2: all gx * gy blocks of a split; 3: plain
   // order (bx fastest), no grouping.
   int gmode, gsz;
+  // ring-staged body (wgrad_ring_loop): tiles arrive by LDS-DMA
+  int ring;
 };
 
 // linear block id -> (bx, by, bz); false: padding id of the grouped order
@@ -90,7 +92,7 @@ __device__ __forceinline__ act8 join(s16x4 lo, s16x4 hi) {
 
 // MFMA work of one staged tile: every wave reads its transposed fragments from
 // the row-major LDS images and accumulates its taps.
-template <int R, int TPW, bool ROWSPLIT, int TT, bool ALLT>
+template <int R, int TPW, bool ROWSPLIT, int TT, int ALLT>
 __device__ __forceinline__ void wgrad_compute(const WgradArgs& a,
                                               const uint16_t* ldsX,
                                               const uint16_t* ldsG,
@@ -212,16 +214,360 @@ __device__ __forceinline__ void colsum_tile(const uint16_t* ldsG, int m0,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Ring-staged K' sweep of the stride-2, 24-tap, one-sample-per-tile form (the
+// critic's and the generator's conv layers: every wave owns three live taps).
+//
+//   * staging is LDS-DMA (global_load_lds_dwordx4): no staging registers, no
+//     LDS store instructions, and NS = 4 tiles in flight instead of one.  A
+//     tile is NP 1-KiB pieces -- the x window as [parity][WRP rows][64 B], then
+//     g as [TT rows][128 B], both unpadded -- and wave w issues pieces w, w + 8,
+//     ...: lane L lands on bytes [16 L, 16 L + 16) of the piece and fetches the
+//     16-byte group that belongs there after the swizzle.
+//   * unpadded rows need a swizzle for conflict-free transpose reads (a 32-lane
+//     half reads 8 rows x 32 B): x rows swap their two 32-byte chunks on row
+//     bit 2, g rows XOR their chunk index with row bits 1-2.
+//   * the loop is software-pipelined over K-steps of 32 rows with two register
+//     fragment sets: [reads of step k + 1 | 24 MFMAs of step k | wait].  The
+//     one barrier per tile sits in front of the LAST step: every wave has then
+//     issued (and waited for) all its reads of tile i, so the barrier both
+//     publishes tile i + 1 (each wave first waits for its own DMAs of it) and
+//     frees tile i's slot for the DMA of tile i + NS.
+//   * reads and MFMAs are inline assembly (see cg_common.h): the compiler
+//     would wait for every LDS-DMA in flight before an LDS read it can see.
+// ---------------------------------------------------------------------------
+template <int TT>
+struct RingGeom {
+  static constexpr int WRP = (TT + 11 + 7) / 8 * 8;  // LDS rows per source-row parity
+  static constexpr int XB = 2 * WRP * 64;
+  static constexpr int GB = TT * 128;
+  static constexpr int STAGE = XB + GB;
+  static constexpr int NPX = XB / 1024;
+  static constexpr int NP = STAGE / 1024;
+  static constexpr int NS = 4;
+  static constexpr int NMIN = NP / 8;       // pieces every wave issues per tile
+  static_assert(XB % 1024 == 0 && GB % 1024 == 0, "whole DMA pieces");
+  static_assert(WRP % 8 == 0, "the parity offset keeps row bit 2");
+};
+
+template <int OFF>
+__device__ __forceinline__ void lds_tr_read(s16x4& d, int addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+
+struct RingFrags {  // two sets: the running K-step's and the next one's
+  s16x4 al[2][6], ah[2][6];  // x: group = (tap slot, 16-channel half), K rows 0-15 / 16-31
+  s16x4 bl[2][4], bh[2][4];  // g: 16-column group
+};
+
+template <int TT>
+__device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
+                                                unsigned char* smem, int bx,
+                                                int by, int bz, int gz,
+                                                bool do_bias,
+                                                f32x4 (&acc)[3][2][4],
+                                                float& bs0, float& bs1) {
+  using G = RingGeom<TT>;
+  using std::integral_constant;
+  constexpr int KSTEPS = TT / 32;
+  static_assert(KSTEPS % 2 == 0, "a tile starts on fragment set 0");
+  const int n_i = bz < a.ntiles ? (a.ntiles - bz + gz - 1) / gz : 0;
+  if (n_i == 0) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15;
+  const int g4 = lane >> 4;
+  const int q = r16 >> 2;
+  const int p = r16 & 3;
+  const int cx0 = bx * 32;
+  const int cg0 = by * 64;
+  const int lds0 = (int)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  // ---- DMA pieces of this lane (fixed across tiles) ---------------------------
+  // x slot k -> piece 8 k + wave (the last slot only on the first NPX % 8 waves),
+  // g slot k -> piece NPX + 8 k + wave.  Per lane: dk = source-row delta from
+  // the tile's first window row, pre = byte offset of its 16-byte group from
+  // that row; og = byte offset from the tile's first g row.  Lanes past the
+  // channel pitch carry an out-of-range offset (they fetch zeros).
+  constexpr int NXF = G::NPX / 8, NXT = G::NPX % 8, NGF = (G::NP - G::NPX) / 8;
+  static_assert((G::NP - G::NPX) % 8 == 0, "g pieces split evenly over the waves");
+  const int rowb = a.Cx * 2;  // bytes per x row
+  int dk[NXF + 1], pre[NXF + 1], og[NGF];
+#pragma unroll
+  for (int k = 0; k <= NXF; ++k) {
+    const int rho = (k * 8 + wave) * 16 + (lane >> 2);
+    const int c4 = lane & 3;
+    const int par = rho >= G::WRP ? 1 : 0;
+    const int wr = rho - par * G::WRP;
+    const int ch = (c4 >> 1) ^ ((rho >> 2) & 1);
+    const int col = cx0 + (ch * 2 + (c4 & 1)) * 8;
+    dk[k] = 2 * wr + par;
+    pre[k] = dk[k] * rowb + col * 2;
+    if (col >= a.Cx) {  // past the channel pitch: zeros on both paths below
+      dk[k] = -(1 << 28);
+      pre[k] = -1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NGF; ++k) {
+    const int r = (k * 8 + wave) * 8 + (lane >> 3);
+    const int c8 = lane & 7;
+    const int ch = (c8 >> 1) ^ ((r >> 1) & 3);
+    const int col = cg0 + (ch * 2 + (c8 & 1)) * 8;
+    og[k] = col < a.Cg ? (r * a.Cg + col) * 2 : -1;
+  }
+  // Running coordinates of the next tile to issue (tiles go out in order, gz
+  // apart): sample b, tile-in-sample ut, and the sample's shuffle segment --
+  // no division in the loop.  The (at most 64: checked on the host) per-segment
+  // shifts sit in one VGPR, lane = segment, and are picked with v_readlane: a
+  // load in the loop would be a vector load the compiler waits for with
+  // vmcnt(0), i.e. for every DMA in flight.
+  const int tps = a.Lu / TT;  // tiles per sample
+  const int step_b = gz / tps, step_t = gz - step_b * tps;
+  int nb = bz / tps, nut = bz - nb * tps;
+  int nsb = 0, nrb = 0;
+  int shv = 0;
+  if (a.shifts) {
+    nsb = nb / a.seg_size;
+    nrb = nb - nsb * a.seg_size;
+    const int nsh = (a.nB + a.seg_size - 1) / a.seg_size;
+    if (lane < nsh) shv = a.shifts[lane];
+  }
+  // The DMA is the buffer form (buffer_load_dwordx4 ... lds): a 32-bit per-lane
+  // offset + a scalar offset against a resource descriptor, and a lane whose
+  // offset is past num_records fetches ZEROS -- padding rows need no zero page
+  // and no 64-bit select.  (The address arithmetic of the global form, ~20 VALU
+  // + exec-masked branches per piece, was 3/4 of the staging cost.)  Interior
+  // tiles (no padding, no reflection in the window) use `pre` as it is; edge
+  // tiles recompute the row, branch-free.
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(a.x), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(a.g), 0, 0x7fffffff, 0x00020000);
+  auto dma = [&](const __amdgpu_buffer_rsrc_t& r, int soff, int piece, unsigned vo,
+                 unsigned so) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        r, (__attribute__((address_space(3))) void*)(smem + soff + piece * 1024), 16,
+        (int)vo, (int)so, 0, 0);
+  };
+  auto issue_tile = [&](int soff) {
+    const int b = nb;
+    const int u0 = nut * TT;
+    const int sft = a.shifts ? __builtin_amdgcn_readlane(shv, nsb) : 0;
+    {  // advance
+      nut += step_t;
+      int db = step_b;
+      if (nut >= tps) {
+        nut -= tps;
+        ++db;
+      }
+      nb += db;
+      if (a.shifts) {
+        nrb += db;
+        while (nrb >= a.seg_size) {
+          nrb -= a.seg_size;
+          ++nsb;
+        }
+      }
+    }
+    const int srow0 = 2 * u0 + a.off;
+    // no window row (of the WRP staged per parity) is padding or reflected
+    const bool interior = srow0 + (sft < 0 ? sft : 0) >= 0 &&
+                          srow0 + 2 * G::WRP - 1 + (sft > 0 ? sft : 0) < a.Lx;
+    const unsigned xsample = (unsigned)b * (unsigned)(a.Lx * rowb);
+    if (interior) {
+      const unsigned xs = xsample + (unsigned)((srow0 + sft) * rowb);
+#pragma unroll
+      for (int k = 0; k < NXF; ++k) dma(rx, soff, k * 8 + wave, (unsigned)pre[k], xs);
+      if (NXT && wave < NXT) dma(rx, soff, NXF * 8 + wave, (unsigned)pre[NXF], xs);
+    } else {
+      // source row of window row d: u = |srow0 + d + sft| reflected at Lx - 1
+      // (PhaseShuffle, cg_common.h shuffle_src), zeros where srow0 + d is padding
+      auto edge = [&](int k) {
+        const int sr = srow0 + dk[k];
+        int u = sr + sft;
+        u = u < 0 ? -u : u;
+        const int v = 2 * (a.Lx - 1) - u;
+        u = v < u ? v : u;
+        unsigned vo = (unsigned)((u - dk[k]) * rowb) + (unsigned)pre[k];
+        asm volatile("" : "+v"(vo));  // (computed on every lane: no exec-masked region)
+        return (unsigned)sr < (unsigned)a.Lx ? vo : 0xffffffffu;
+      };
+#pragma unroll
+      for (int k = 0; k < NXF; ++k) dma(rx, soff, k * 8 + wave, edge(k), xsample);
+      if (NXT && wave < NXT) dma(rx, soff, NXF * 8 + wave, edge(NXF), xsample);
+    }
+    const unsigned gs = (unsigned)(b * a.Lu + u0) * (unsigned)(a.Cg * 2);
+#pragma unroll
+    for (int k = 0; k < NGF; ++k) dma(rg, soff, G::NPX + k * 8 + wave, (unsigned)og[k], gs);
+  };
+
+  // ---- fragment addresses (absolute LDS bytes, slot 0) ------------------------
+  int abase[3][2], bbase[4];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int tap = wave + 8 * s;
+    const int row0 = (tap & 1) * G::WRP + (tap >> 1) + 4 * g4 + q;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+      abase[s][mt] = lds0 + row0 * 64 + ((mt ^ ((row0 >> 2) & 1)) * 32) + 8 * p;
+  }
+  {
+    const int rowb = 4 * g4 + q;
+    const int sw = (rowb >> 1) & 3;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      bbase[nt] = lds0 + G::XB + rowb * 128 + ((nt ^ sw) * 32) + 8 * p;
+  }
+  // Fragment traffic of one K-step (32 rows): six x fragments (group g = tap
+  // slot g / 2, 16-channel half g % 2; 4 MFMAs each) and four g fragments (all
+  // 24 MFMAs), 20 transpose reads, double-buffered in registers.  The reads of
+  // the next step go out between the first MFMAs of the running one, two per
+  // MFMA: all of them in front of the MFMAs hold the wave -- and, with all eight
+  // waves in that burst at once, every matrix pipe -- for the LDS queue (measured:
+  // +1.3 % .. +5 % per launch); spread thinner (one per MFMA, or a rolling
+  // single-buffered prefetch with counted waits) the last ones return too late.
+  RingFrags f;
+  // read r (0..19) of K-step KS into set SET: g fragments first, then x in MFMA order
+  auto read_one = [&](auto set_tag, auto ks_tag, auto r_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+    constexpr int KS = decltype(ks_tag)::value;
+    constexpr int r = decltype(r_tag)::value;
+    if constexpr (r < 8) {
+      constexpr int nt = r >> 1;
+      if constexpr ((r & 1) == 0)
+        lds_tr_read<KS * 32 * 128>(f.bl[SET][nt], bbase[nt]);
+      else
+        lds_tr_read<(KS * 32 + 16) * 128>(f.bh[SET][nt], bbase[nt]);
+    } else {
+      constexpr int g = (r - 8) >> 1;
+      if constexpr ((r & 1) == 0)
+        lds_tr_read<KS * 32 * 64>(f.al[SET][g], abase[g >> 1][g & 1]);
+      else
+        lds_tr_read<(KS * 32 + 16) * 64>(f.ah[SET][g], abase[g >> 1][g & 1]);
+    }
+  };
+  // the step on set SET; its reads fetch K-step KSN into the other set for the
+  // step after; `mid` runs behind MFMA 11 (the DMA issue of a tile's last step)
+  auto step = [&](auto set_tag, auto ksn_tag, auto&& mid) {
+    constexpr int SET = decltype(set_tag)::value;
+    using NSET = integral_constant<int, SET ^ 1>;
+    static_for<24>([&](auto j_tag) {
+      constexpr int j = decltype(j_tag)::value;
+      constexpr int g = j >> 2, nt = j & 3;
+      mfma_acc(acc[g >> 1][g & 1][nt], join(f.al[SET][g], f.ah[SET][g]),
+               join(f.bl[SET][nt], f.bh[SET][nt]));
+      if constexpr (j < 10) {
+        read_one(NSET{}, ksn_tag, integral_constant<int, 2 * j>{});
+        read_one(NSET{}, ksn_tag, integral_constant<int, 2 * j + 1>{});
+      }
+      if constexpr (j == 11) mid();
+    });
+    lds_wait();
+  };
+  // bias gradient: column sums of the g tile in slot `soff` (asm reads, as the
+  // fragments: consumed after the phase's wait)
+  constexpr int RPG = TT / 16;
+  const int cp = (tid & 31) * 2;
+  const int cs_row = (tid >> 5) * RPG;
+  uint32_t csw[RPG];
+  auto colsum_read = [&](int soff) {
+#pragma unroll
+    for (int k = 0; k < RPG; ++k) {
+      const int row = cs_row + k;
+      const int addr = lds0 + soff + G::XB + row * 128 +
+                       (((cp >> 4) ^ ((row >> 1) & 3)) * 32) + (cp & 15) * 2;
+      asm volatile("ds_read_b32 %0, %1" : "=v"(csw[k]) : "v"(addr));
+    }
+  };
+  auto colsum_add = [&](int tile) {
+#pragma unroll
+    for (int k = 0; k < RPG; ++k)
+      if ((long long)tile * TT + cs_row + k < a.bias_rows) {
+        bs0 += act_lo(csw[k]);
+        bs1 += act_hi(csw[k]);
+      }
+  };
+
+  // ---- prologue: NS tiles in flight, fragments of tile 0 / step 0 -------------
+#pragma unroll
+  for (int j = 0; j < G::NS; ++j)
+    if (j < n_i) issue_tile(j * G::STAGE);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  static_for<20>([&](auto r_tag) {
+    read_one(integral_constant<int, 0>{}, integral_constant<int, 0>{}, r_tag);
+  });
+  lds_wait();
+
+  {
+    int soff = 0;  // ring slot (byte offset) of tile i
+    for (int i = 0; i < n_i; ++i) {
+      const int tile = bz + i * gz;
+      const bool bias_tile = do_bias && (long long)tile * TT < a.bias_rows;
+      if (bias_tile) colsum_read(soff);
+      static_for<KSTEPS>([&](auto k_tag) {
+        constexpr int k = decltype(k_tag)::value;
+        using SET = integral_constant<int, k & 1>;
+        if constexpr (k + 1 < KSTEPS) {
+          step(SET{}, integral_constant<int, k + 1>{}, [&] {
+            // (the column-sum reads went out before step 0's: back by now)
+            if constexpr (k == 1) {
+              if (bias_tile) colsum_add(tile);
+            }
+          });
+        } else {
+          // all but the DMAs of the tiles after i + 1 have landed (this wave's
+          // share; the barrier makes it everyone's)
+          const int later = n_i - i - 2;
+          if (later >= 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::NMIN) : "memory");
+          else if (later == 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NMIN) : "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          const int delta = soff == (G::NS - 1) * G::STAGE
+                                ? -(G::NS - 1) * G::STAGE
+                                : G::STAGE;
+#pragma unroll
+          for (int s = 0; s < 3; ++s) {
+            abase[s][0] += delta;
+            abase[s][1] += delta;
+          }
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) bbase[nt] += delta;
+          // reads: step 0 of tile i + 1 (after the last tile: resident LDS
+          // nobody uses); the DMA of tile i + NS goes into tile i's slot
+          step(SET{}, integral_constant<int, 0>{}, [&] {
+            if constexpr (k == 1) {
+              if (bias_tile) colsum_add(tile);
+            }
+            if (i + G::NS < n_i) issue_tile(soff);
+          });
+          soff += delta;
+        }
+      });
+    }
+  }
+  // the accumulators are read by ordinary instructions next: let the matrix
+  // pipe drain (the compiler cannot see the MFMAs)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+}
+
+
 // R: source stride (1|2).  TPW: taps per wave.  ROWSPLIT: taps == 1, the waves
 // split the staged rows (TT = 256) instead of the taps (TT = 64).  PIPE: one
 // sample per tile (nseg == 1): tiles are double-buffered in LDS and the next
 // tile's global loads are issued before the current tile's MFMAs.
-// ALLT: every wave owns TPW live taps (taps == 8 * TPW) and a tile is one
+// ALLT (1 | 2): every wave owns TPW live taps (taps == 8 * TPW) and a tile is one
 // sample: wgrad_compute runs its software-pipelined order.
 // (bx, by, bz) / gz: this workgroup's (cx chunk, cg chunk, K' split) and the
 // number of K' splits -- blockIdx / gridDim.z for a single launch, decoded from
 // the linear block id by the multi-layer kernel below.
-template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, bool ALLT>
+template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, int ALLT>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
                                            int bz, int gz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -255,7 +601,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
   const bool do_bias = a.dbias != nullptr && bx == 0;
   float bs0 = 0.f, bs1 = 0.f;
 
-  if (PIPE) {
+  if constexpr (ALLT == 2) {
+    static_assert(R == 2 && TPW == 3 && PIPE && !ROWSPLIT, "ring-staged form");
+    wgrad_ring_loop<TT>(a, smem, bx, by, bz, gz, do_bias, acc, bs0, bs1);
+  } else if (PIPE) {
     // per-thread piece coordinates (fixed across tiles)
     const int xq8 = tid & 3;
     const int xc = cx0 + xq8 * 8;
@@ -439,7 +788,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
   }
 }
 
-template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, bool ALLT>
+template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, int ALLT>
 __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a, int gz) {
   int bx, by, bz;
   if (!wgrad_block(a, gz, blockIdx.x, bx, by, bz)) return;
@@ -511,16 +860,17 @@ struct WgradMulti {
   WgradArgs a[kMaxBatch];
 };
 
-template <int R, int TPW>
+// ALLT: 1 register-staged tiles, 2 the LDS-DMA ring (all layers of the launch)
+template <int R, int TPW, int ALLT>
 __global__ __launch_bounds__(512) void wgrad_multi_kernel(WgradMulti m) {
   for (int li = 0; li < m.n; ++li) {
     const int gz = m.gz[li];
     int bx, by, bz;
     if (wgrad_block(m.a[li], gz, blockIdx.x, bx, by, bz)) {
       if (m.tt[li] == 128)
-        wgrad_body<R, TPW, false, true, 128, true>(m.a[li], bx, by, bz, gz);
+        wgrad_body<R, TPW, false, true, 128, ALLT>(m.a[li], bx, by, bz, gz);
       else
-        wgrad_body<R, TPW, false, true, 64, true>(m.a[li], bx, by, bz, gz);
+        wgrad_body<R, TPW, false, true, 64, ALLT>(m.a[li], bx, by, bz, gz);
     }
     __syncthreads();  // LDS is reused by the next item
   }
@@ -541,7 +891,7 @@ inline unsigned wgrad_grid(const WgradArgs& a, int gz) {
   return (unsigned)((groups + 7) / 8 * 8 * a.gsz);
 }
 
-template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, bool ALLT = false>
+template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, int ALLT = 0>
 int launch_wgrad1(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -563,6 +913,13 @@ int launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, bool pipe, int tt,
   constexpr int T0 = ROWSPLIT ? 256 : 64;
   // pipe implies one sample per tile (nseg == 1)
   const bool allt = !ROWSPLIT && pipe && a.taps == 8 * TPW && a.nseg == 1;
+  if constexpr (R == 2 && TPW == 3 && !ROWSPLIT) {
+    if (a.ring && allt) {
+      if (tt == 128)
+        return launch_wgrad1<R, TPW, ROWSPLIT, true, 128, 2>(a, grid, 2 * lds, s);
+      return launch_wgrad1<R, TPW, ROWSPLIT, true, 64, 2>(a, grid, 2 * lds, s);
+    }
+  }
   if (!ROWSPLIT && tt == 128) {  // only chosen with pipe
     if (allt)
       return launch_wgrad1<R, TPW, ROWSPLIT, true, ROWSPLIT ? 256 : 128,
@@ -585,7 +942,7 @@ struct WgradPlan {
   WgradArgs a;
   int gx, gy, nsplit, TT, R, tpw;
   long long part_elems;
-  size_t lds;
+  size_t lds, ring_lds;
   bool pipe, rowsplit;
 };
 
@@ -632,6 +989,17 @@ int plan_wgrad(const cg_wgrad_desc* d, WgradPlan& p) {
       ((size_t)R * a.nseg * a.WR * kPitchX + (size_t)TT * kPitchG) * 2;
   if (lds > 160 * 1024) return CG_EINVAL;
   p.pipe = a.nseg == 1 && 2 * lds <= 160 * 1024;
+  // ring-staged sweep (LDS-DMA, 4 tiles in flight): the stride-2 24-tap form
+  // with one sample per tile
+  a.ring = 0;
+  p.ring_lds = 0;
+  if (!rowsplit && p.pipe && d->taps == 24 && !d->classic_staging &&
+      (long long)d->nB * d->Lx * d->Cx * 2 < (1ll << 31) &&
+      (long long)d->nB * d->Lu * d->Cg * 2 < (1ll << 31) &&
+      (!d->shifts || (d->nB + d->seg_size - 1) / d->seg_size <= 64)) {
+    a.ring = 1;
+    p.ring_lds = TT == 128 ? 4 * RingGeom<128>::STAGE : 4 * RingGeom<64>::STAGE;
+  }
   p.gx = (d->Cx_real + 31) / 32;
   p.gy = (d->Cg_real + 63) / 64;
   int nsplit = d->nsplit;
@@ -645,7 +1013,10 @@ int plan_wgrad(const cg_wgrad_desc* d, WgradPlan& p) {
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   if (nsplit < 1) nsplit = 1;
   p.nsplit = nsplit;
-  p.TT = TT; p.R = R; p.lds = lds; p.rowsplit = rowsplit;
+  p.TT = TT; p.R = R; p.rowsplit = rowsplit;
+  // (pipelined launches ask for 2 * p.lds bytes: two register-staged tiles, or
+  // the ring)
+  p.lds = a.ring ? p.ring_lds / 2 : lds;
   p.tpw = rowsplit ? 1 : (d->taps <= 8 ? 1 : (d->taps <= 16 ? 2 : 3));
   a.part = nullptr;
   a.pgx = p.gx; a.pgy = p.gy;
@@ -708,17 +1079,17 @@ int launch_plan(const WgradPlan& p, hipStream_t s) {
   return launch_wgrad<2, 3, false>(p.a, grid, p.lds, p.pipe, p.TT, s);
 }
 
-template <int TPW>
+template <int TPW, int ALLT = 1>
 int launch_multi(const WgradMulti& m, int blocks, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&wgrad_multi_kernel<2, TPW>),
+        reinterpret_cast<const void*>(&wgrad_multi_kernel<2, TPW, ALLT>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  CG_LAUNCH_PROF(CG_FAMILY_WGRAD, (wgrad_multi_kernel<2, TPW>), dim3(blocks),
+  CG_LAUNCH_PROF(CG_FAMILY_WGRAD, (wgrad_multi_kernel<2, TPW, ALLT>), dim3(blocks),
                  dim3(512), lds, s, m);
   CG_LAUNCH_CHECK();
 }
@@ -758,7 +1129,7 @@ extern "C" int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream)
     // the fused kernel is the pipelined stride-2 instantiation with every tap
     // live; anything else is launched on its own
     if (p.rowsplit || !p.pipe || p.a.taps != 8 * p.tpw || p.a.nseg != 1 ||
-        p.tpw != plans[0].tpw)
+        p.tpw != plans[0].tpw || p.a.ring != plans[0].a.ring)
       fuse = false;
   }
   if (!fuse) {
@@ -784,7 +1155,10 @@ extern "C" int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream)
   switch (plans[0].tpw) {
     case 1: rc = launch_multi<1>(m, blocks, lds, s); break;
     case 2: rc = launch_multi<2>(m, blocks, lds, s); break;
-    default: rc = launch_multi<3>(m, blocks, lds, s); break;
+    default:
+      rc = plans[0].a.ring ? launch_multi<3, 2>(m, blocks, lds, s)
+                           : launch_multi<3>(m, blocks, lds, s);
+      break;
   }
   if (rc) return rc;
   ReduceArgs ra;

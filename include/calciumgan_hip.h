@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 11
+#define CG_ABI_VERSION 12
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -252,6 +252,7 @@ typedef struct cg_wgrad_desc {
   int nsplit;        /* 0 = choose */
   int tile_rows;     /* 0 = choose; 64 or 128 rows of (b,u) per staged tile */
   int no_xcd_group;  /* 1: plain block order instead of the XCD-grouped one (A/B runs) */
+  int classic_staging; /* 1: register-staged tiles instead of the LDS-DMA ring (A/B runs) */
   float* dbias;      /* optional f32 [Cg_real]: += sum of g over its first
                         bias_rows (b,u) rows -- the conv bias gradient, taken
                         from the g tiles already staged in LDS */

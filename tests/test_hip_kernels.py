@@ -476,14 +476,22 @@ WGRAD_CASES = [
     (4, 16, 64, 72, 8, 2, True),
     (6, 256, 64, 128, 24, 2, True),
     (96, 8, 128, 160, 24, 32, True),
+    # ring-staged sweep: many tiles per workgroup (the ring wraps), interior and
+    # edge tiles, a channel pitch that is not a whole 64-column chunk
+    (5, 1024, 40, 72, 24, 2, True),
+    (9, 512, 64, 64, 24, 3, True),
+    (70, 128, 32, 64, 24, 2, True),
 ]
 
 
+@pytest.mark.parametrize('classic', [0, 1])
 @pytest.mark.parametrize('partials', [False, True])
 @pytest.mark.parametrize('nB,L,Ci,Co,k,seg,use_shift', WGRAD_CASES)
-def test_conv_wgrad_bitexact(nB, L, Ci, Co, k, seg, use_shift, partials):
+def test_conv_wgrad_bitexact(nB, L, Ci, Co, k, seg, use_shift, partials, classic):
   """partials = True: the K' splits store partial sums that a second launch
-  adds into dw (which must ACCUMULATE: dw starts at 1); False: f32 atomics."""
+  adds into dw (which must ACCUMULATE: dw starts at 1); False: f32 atomics.
+  classic = 1: register-staged tiles instead of the LDS-DMA ring (the 24-tap
+  cases whose samples span whole tiles take the ring by default)."""
   rng = np.random.RandomState(7)
   x = H.int_tensor(rng, (nB, L, Ci), -2, 2)
   dy = H.int_tensor(rng, (nB, L // 2, Co), -2, 2)
@@ -504,6 +512,7 @@ def test_conv_wgrad_bitexact(nB, L, Ci, Co, k, seg, use_shift, partials):
                        shifts=sh if use_shift else None, seg_size=seg,
                        dbias=dbias, bias_rows=nb_bias * (L // 2),
                        slot=0 if partials else None)
+  d.classic_staging = classic
   if partials:
     d.nsplit = 3  # several K' splits whatever the shape
     need = _lib.load().cg_wgrad_partials_elems(ctypes.byref(d))

@@ -4,7 +4,7 @@
   python tools/bench_conv.py conv  R taps nB Lx Cx N [CK] [small] [epi] [f32]
                                    [ksteps] [rowsumsq] [sp]
 (stride-2 operands are packed parity-major; sp = 1: split-parity staging)
-  python tools/bench_conv.py wgrad R taps nB Lx Cx Cg [nsplit] [tile_rows] [no_xcd_group]
+  python tools/bench_conv.py wgrad R taps nB Lx Cx Cg [nsplit] [tile_rows] [no_xcd_group] [classic_staging]
 Lx is the source length; outputs Lu = Lx/2 (R=2) or Lx (R=1, 2 phases when
 taps > 1)."""
 import ctypes
@@ -90,11 +90,12 @@ def main():
     d.nsplit = nsplit
     d.tile_rows = a[7] if len(a) > 7 else 0
     d.no_xcd_group = a[8] if len(a) > 8 else 0
+    d.classic_staging = a[9] if len(a) > 9 else 0
     st = nets._stream()
     t = timeit(lambda: _lib.call('cg_wgrad', ctypes.byref(d), st))
     fl = 2.0 * nB * Lu * Cg * taps * Cx
-    print('wgrad R%d taps%d nB%d Lu%d Cx%d Cg%d nsplit%d tile%d plain%d: %.1f us  %.1f TF/s'
-          % (R, taps, nB, Lu, Cx, Cg, nsplit, d.tile_rows, d.no_xcd_group,
+    print('wgrad R%d taps%d nB%d Lu%d Cx%d Cg%d nsplit%d tile%d plain%d classic%d: %.1f us  %.1f TF/s'
+          % (R, taps, nB, Lu, Cx, Cg, nsplit, d.tile_rows, d.no_xcd_group, d.classic_staging,
              t * 1e6, fl / t / 1e12))
 
 
