@@ -50,6 +50,3 @@ struct ConvArgs {
 int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
                       int ksplit, bool dry, hipStream_t stream);
 
-// device address of 64 zero bytes (the source LDS-DMA lanes fetch for padding
-// rows); nullptr if the symbol lookup failed
-const unsigned char* cg_zero_page();

@@ -13,14 +13,15 @@
 //     K-step k+1 are issued BEFORE the MFMAs of K-step k, so LDS latency, the
 //     per-stage barrier and the DMA waits sit in the shadow of 16-32 queued
 //     MFMAs instead of in front of them;
-//   * every global -> LDS byte moves by LDS-DMA (global_load_lds_dwordx4), the
-//     source window included: a window row of one 32-channel chunk is 64 B, a
+//   * every global -> LDS byte moves by LDS-DMA (buffer_load_dwordx4 ... lds:
+//     a 32-bit per-lane offset + a scalar offset, no address arithmetic in the
+//     loop), the source window included: a window row of one 32-channel chunk is 64 B, a
 //     DMA piece 16 rows; rows cannot be padded (the DMA writes lane-linear), so
 //     the four 16-byte chunks of a row are XOR-swizzled by bit 2 of the row
 //     (slot = chunk ^ 2*((row >> 2) & 1)): conflict-free ds_read_b128 for the
 //     16x16x32 A operand at every tap offset.  Zero padding of 'same' and rows
-//     past the batch come from a 64-byte zero page; the PhaseShuffle gather is
-//     the per-lane source address;
+//     past the batch are offsets past the descriptor's num_records (the load
+//     returns zeros); the PhaseShuffle gather is the per-lane source offset;
 //   * a stride-2 window is walked one source-row parity at a time (the packed
 //     operand is parity-major), so stride 1 and stride 2 share one loop: a PASS
 //     = (channel chunk, parity) = taps/stride taps over a (rows + taps/stride
@@ -34,10 +35,6 @@
 
 namespace {
 
-// source of padding rows (a __device__ array is zero-initialised); kernels get
-// its address as an argument (in-kernel it would be a GOT load per use)
-__device__ __attribute__((aligned(64))) uint4 g_zero_page[4];
-
 struct SwpArgs {
   ConvArgs c;
   int tpp;           // taps per pass (taps / stride)
@@ -50,7 +47,6 @@ struct SwpArgs {
   int nst;           // weight stages per full pass (tpp / 2)
   int total_stages;
   int npad_rows;     // rows of the packed operand (N rounded up to 128)
-  const unsigned char* zero;  // 64 zero bytes
   float inv_WRs;
 };
 
@@ -66,8 +62,8 @@ __device__ __forceinline__ int sw64(int byte) {
 
 // R: source stride.  WM x WN waves (4 or 8); wave tile (16 * MT) x 64.
 // LN: CG_EPI_LN_LRELU (LayerNorm + LeakyReLU in the epilogue; 128-column tiles).
-template <int R, int WM, int WN, int MT, bool LN = false>
-__global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) {
+template <int R, int WM, int WN, int MT, bool LN>
+__device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   static_assert(WM * WN == 4 || WM * WN == 8, "one or two waves per SIMD");
   static_assert(!LN || WN == 2, "the fused LayerNorm needs a 128-column tile");
   const ConvArgs& a = pa.c;
@@ -135,13 +131,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
   // piece j of the window of pass p -> buffer p & 1, bytes [j KiB, (j+1) KiB):
   // lane L lands on (row 16 j + L/4, slot L & 3) and fetches the chunk that
   // slot holds after the swizzle.  Wave w owns pieces j = k NW + w; the source
-  // address of (k, source-row parity) at channel chunk 0 is computed ONCE here
-  // (per-lane 64-bit pointers; the hot loop only adds the chunk offset), with
-  // the zero page standing in for padding rows and rows past the batch.
+  // offset of (k, source-row parity) at channel chunk 0 is computed ONCE here
+  // (the hot loop only passes the chunk offset as the scalar operand).
   const int pslot = lane & 3;
   const int full_passes = (a.nchunks - (a.narrow ? 1 : 0)) * R;
-  // (kept as 32-bit offsets from x in 16-byte units, ~0 = zero page: half the
-  // registers of 64-bit pointers, and nothing for the compiler to hoist)
+  // (byte offsets from the tile's first sample; ~0 = padding: the buffer form
+  // of the DMA fetches zeros for an offset past num_records, so there is no zero
+  // page and no 64-bit select in the loop)
   uint32_t aoff[KPW][R];
   // logical 16-byte chunk this lane fetches: pieces start at multiples of 16
   // rows, so row bit 2 is lane bit 4 for every piece
@@ -163,13 +159,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
         int srow = R * (u0 + wr) + off + par;
         if (srow >= 0 && srow < a.Lx) {
           if (a.shifts) srow = shuffle_src(srow, sft, a.Lx);
-          o = (uint32_t)((((long long)b * a.Lx + srow) * a.Cx + q * 8) >> 3);
+          o = (uint32_t)(((seg * a.Lx + srow) * a.Cx + q * 8) * 2);
         }
       }
       aoff[k][par] = o;
     }
   }
-  const unsigned char* xbytes = reinterpret_cast<const unsigned char*>(a.x);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(a.x + (long long)b0 * a.Lx * a.Cx), 0, 0x7fffffff,
+      0x00020000);
   // issue slot k of pass p (k compile-time: the offset arrays stay in registers)
   auto issue_a_piece = [&](int p, int k, uint32_t o0, uint32_t o1, int q) {
     uint32_t o;
@@ -181,19 +179,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
     } else {
       // narrow last chunk: chunk q of a row = the first 8-channel group of
       // source-row parity q (q < 2; the rest of the row is never read)
-      o = q >= 2 ? ~0u : ((q & 1) ? o1 : o0);
-      add = (a.nchunks - 1) * 64 - q * 16;
+      const uint32_t sel = (q & 1) ? o1 : o0;
+      o = (q >= 2 || sel == ~0u) ? ~0u : sel - q * 16;
+      add = (a.nchunks - 1) * 64;
     }
-    // (opaque to LICM: hoisted out of the stage loop, the 64-bit addresses of
-    // all slots would sit in registers for a whole pass)
+    // (opaque to LICM: hoisted out of the stage loop, the offsets of all slots
+    // would sit in registers for a whole pass)
     asm volatile("" : "+v"(o));
-    const unsigned char* src =
-        o == ~0u ? pa.zero : xbytes + ((unsigned long long)o << 4) + add;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)src,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rx,
         (__attribute__((address_space(3))) void*)(ldsA + (p & 1) * ABYTES +
                                                   (k * NW + wave) * 1024),
-        16, 0, 0);
+        16, (int)o, add, 0, 0);
   };
   // piece slot K (compile-time) of pass p; returns 1 if this wave owns it
   auto issue_a_slot = [&](int p, auto k_tag) {
@@ -220,7 +217,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
   // ---- weight stages ---------------------------------------------------------
   // wave w issues pieces w*NBW + i of a stage: lane L lands at slot byte
   // piece*1024 + L*16 = (row, chunk slot c') and fetches chunk c' ^ swz(row)
-  const uint16_t* dsrc[NBW];
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(wp), 0, 0x7fffffff, 0x00020000);
+  int boff[NBW];
 #pragma unroll
   for (int i = 0; i < NBW; ++i) {
     const int pe = ((wave * NBW + i) * 1024 + lane * 16) / 2;  // element offset
@@ -229,19 +228,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
     const int c = cs ^ ((row >> 1) & 7);
     row += n0;
     if (row >= pa.npad_rows) row = pa.npad_rows - 1;  // columns past N: unused
-    dsrc[i] = wp + (long long)row * a.Kpack + c * 8;
+    boff[i] = (row * a.Kpack + c * 8) * 2;
   }
-  // (running source pointers: + one 64-deep stage per issue)
+  // (one running scalar offset: + one 64-deep stage per issue)
+  int bstage = 0;
   auto issue_b = [&](int slot_idx) {
     uint16_t* slot = ldsB + slot_idx * kBufB;
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)dsrc[i],
-          (__attribute__((address_space(3))) void*)(slot + (wave * NBW + i) * 512),
-          16, 0, 0);
-      dsrc[i] += KS * 32;
-    }
+    for (int i = 0; i < NBW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rw, (__attribute__((address_space(3))) void*)(slot + (wave * NBW + i) * 512),
+          16, boff[i], bstage, 0, 0);
+    bstage += KS * 32 * 2;
   };
 
   // ---- fragment addresses ----------------------------------------------------
@@ -605,6 +603,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) 
   }
 }
 
+// (the body is a __device__ function: with the buffer-resource builtins written
+// directly in a __global__ template the host pass emits no stub for it)
+template <int R, int WM, int WN, int MT, bool LN = false>
+__global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) {
+  swconv_swp_body<R, WM, WN, MT, LN>(pa);
+}
+
 template <int R, int WM, int WN, int MT, bool LN = false>
 int launch_swp(const SwpArgs& pa, dim3 grid, size_t lds, bool dry, hipStream_t s) {
   if (dry) return 0;
@@ -623,14 +628,6 @@ int launch_swp(const SwpArgs& pa, dim3 grid, size_t lds, bool dry, hipStream_t s
 
 }  // namespace
 
-const unsigned char* cg_zero_page() {
-  static const void* zp = nullptr;
-  if (!zp && hipGetSymbolAddress(const_cast<void**>(&zp), HIP_SYMBOL(g_zero_page)) !=
-                 hipSuccess)
-    zp = nullptr;
-  return reinterpret_cast<const unsigned char*>(zp);
-}
-
 int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
                       int ksplit, bool dry, hipStream_t stream) {
   // uniform 32-channel K walk, one tap per K-step; no split-K (the tile
@@ -640,11 +637,8 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   if (ln && (wn != 2 || stride != 1 || a.N > 128)) return CG_EINVAL;
   if (stride == 2 && !a.pmajor) return CG_EINVAL;
   const int nw = wm * wn, tn = wn * 64;
-  const unsigned char* zero_page = cg_zero_page();
-  if (!zero_page) return CG_EINVAL;
   SwpArgs pa;
   pa.c = a;
-  pa.zero = zero_page;
   pa.tpp = a.taps / stride;
   // whole 64-deep stages per pass, and stages 0 .. nst - 3 to issue the next
   // window in
