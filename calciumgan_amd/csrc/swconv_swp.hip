@@ -408,19 +408,14 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
 
   // ---- epilogue: accumulators -> LDS -> whole-line row-contiguous stores ------
   // (the epilogues of swconv_kernel on 16x16 accumulators)
-  __syncthreads();
+  // (global loads first -- bias, mask words -- so that they fly across the
+  // barrier that ends the LDS reads of the K loop)
   float* scr = reinterpret_cast<float*>(smem) + wave * (16 * kSwpScrPitch);
   // fused LayerNorm + LeakyReLU: the row statistics span the two waves that
   // share a row block (wave ^ 1); their partial sums meet in a small LDS table
   // behind the transpose scratch, gamma / beta sit next to it
   float* part = reinterpret_cast<float*>(smem) + NW * 16 * kSwpScrPitch;
   float* lnp = part + NW * 16 * 2;  // gamma[128] | beta[128] (zero past N)
-  if constexpr (LN) {
-    if (tid < 128) {
-      lnp[tid] = tid < a.N ? a.ln_gamma[tid] : 0.f;
-      lnp[128 + tid] = tid < a.N ? a.ln_beta[tid] : 0.f;
-    }
-  }
   const int erow = lane >> 3;
   const int cg8 = lane & 7;
   const bool of32 = !LN && a.out_f32;  // (the LayerNorm form stores bf16)
@@ -434,6 +429,62 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   for (int e = 0; e < 4; ++e) {
     bv[e] = (a.bias && nA + e < a.N) ? a.bias[nA + e] : 0.f;
     bv[4 + e] = (a.bias && nB + e < a.N) ? a.bias[nB + e] : 0.f;
+  }
+  // Row addressing of the plain (non-LayerNorm) forms.  A wave's 16 MT rows lie
+  // in one sample (S >= 16 MT): sample index and output-side phase shift are
+  // wave-uniform, computed once (they were a division and a dependent global
+  // load per 8-row pass).  The LeakyReLU' mask words of all 2 MT passes are
+  // fetched HERE, in front of the transposes: behind each pass's wavefront
+  // fence they were MT exposed global round trips per workgroup, 26 of the 89 us
+  // of a critic input-gradient launch.
+  const int mw0 = m0 + wm * MT * 16;  // first row of this wave
+  const int bw = __builtin_amdgcn_readfirstlane(mw0 / a.Lu);
+  const int uw0 = mw0 - bw * a.Lu;
+  int oshift = 0;
+  if (!LN && a.out_shifts && bw < a.nB) oshift = a.out_shifts[bw / a.out_seg];
+  // output row of tile row r of this wave: element offset of its first column;
+  // to_side: a reflected row of the output-side PhaseShuffle adjoint
+  auto row_target = [&](int r, bool& to_side) {
+    const int u = uw0 + r;
+    int t = a.y_stride * u + y_off;
+    to_side = false;
+    if (a.out_shifts) {
+      if (oshift > 0) {
+        to_side = t >= a.Ly - oshift;
+        t = to_side ? t - (a.Ly - oshift) : t + oshift;
+      } else {
+        to_side = t < -oshift;
+        t = to_side ? t : t + oshift;
+      }
+    }
+    return ((long long)bw * (to_side ? a.side_rows : a.Ly) + t) * a.Cy;
+  };
+  uint2 mka[MT][2], mkb[MT][2];
+  if constexpr (!LN) {
+    if (a.epilogue == CG_EPI_MASK) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int r = mt * 16 + pass * 8 + erow;
+          bool to_side;
+          const long long rowoff = row_target(r, to_side);
+          mka[mt][pass] = make_uint2(0u, 0u);
+          mkb[mt][pass] = make_uint2(0u, 0u);
+          if (mw0 + r < a.M && nA < a.Cy && !to_side) {
+            mka[mt][pass] = *reinterpret_cast<const uint2*>(a.mask + rowoff + nA);
+            if (nB < a.Cy)
+              mkb[mt][pass] = *reinterpret_cast<const uint2*>(a.mask + rowoff + nB);
+          }
+        }
+    }
+  }
+  __syncthreads();
+  if constexpr (LN) {
+    if (tid < 128) {
+      lnp[tid] = tid < a.N ? a.ln_gamma[tid] : 0.f;
+      lnp[128 + tid] = tid < a.N ? a.ln_beta[tid] : 0.f;
+    }
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -516,22 +567,8 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
         }
       }
       if (!LN && m < a.M && nA < a.Cy) {
-        const int b = m / a.Lu;
-        const int u = m - b * a.Lu;
-        int t = a.y_stride * u + y_off;
-        bool to_side = false;
-        if (a.out_shifts) {
-          const int s = a.out_shifts[b / a.out_seg];
-          if (s > 0) {
-            to_side = t >= a.Ly - s;
-            t = to_side ? t - (a.Ly - s) : t + s;
-          } else {
-            to_side = t < -s;
-            t = to_side ? t : t + s;
-          }
-        }
-        const long long rowoff =
-            ((long long)b * (to_side ? a.side_rows : a.Ly) + t) * a.Cy;
+        bool to_side;
+        const long long rowoff = row_target(mt * 16 + row, to_side);
         const f32x4 v0 =
             *reinterpret_cast<const f32x4*>(scr + row * kSwpScrPitch + colA);
         const f32x4 v1 =
@@ -548,9 +585,8 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = act2f(f2act(v[e]));
           }
-          const uint2 ha = *reinterpret_cast<const uint2*>(a.mask + rowoff + nA);
-          const uint2 hb = okB ? *reinterpret_cast<const uint2*>(a.mask + rowoff + nB)
-                               : make_uint2(0u, 0u);
+          const uint2 ha = mka[mt][pass];
+          const uint2 hb = mkb[mt][pass];
           const uint32_t hw[4] = {ha.x, ha.y, hb.x, hb.y};
 #pragma unroll
           for (int e = 0; e < 8; ++e) {

@@ -14,47 +14,38 @@ SRC = os.path.join(ROOT, 'calciumgan_amd', 'csrc')
 OUT = os.path.join(ROOT, 'tools', 'probe', '_abl')
 
 
-def loop_region(s):
-  i0 = s.index('  int gs = 0;\n  int na_prev = 0;')
-  i1 = s.index('  // ---- epilogue: accumulators')
-  return i0, i1
+def no_loop(s):  # prologue + epilogue only
+  a = """  for (int p = 0; p < full_passes; ++p) run_pass(False{}, p);
+  if (a.narrow) run_pass(True{}, full_passes);
+"""
+  assert a in s
+  return s.replace(a, '')
 
 
-def in_loop(s, fn):
-  i0, i1 = loop_region(s)
-  return s[:i0] + fn(s[i0:i1]) + s[i1:]
-
-
-def no_vmwait(s):
-  return in_loop(s, lambda t: re.sub(r'asm volatile\("s_waitcnt vmcnt[^;]*;', ';', t))
-
-
-def no_barrier(s):
-  return in_loop(s, lambda t: t.replace('__builtin_amdgcn_s_barrier();', ''))
-
-
-def no_dma(s):
-  def f(t):
-    t = t.replace('if (gs + 3 < pa.total_stages) issue_b(gs + 3);', '')
-    t = t.replace('na_prev = issue_a_range(p + 1, s * pa.apw, (s + 1) * pa.apw);',
-                  'na_prev = 0;')
-    return t
-  return in_loop(no_vmwait(s), f)
+def no_dma(s):  # no DMA issue inside the passes (stale LDS is read)
+  a = "      if (!last || s + 3 < NSTG) issue_b(s % kSwpRing);\n"
+  b = "        if (!last) {\n          // apw (1 or 2) slots of this wave per issuing stage"
+  assert a in s and b in s
+  s = s.replace(a, '')
+  return s.replace(b, "        if (false) {\n          // apw (1 or 2) slots of this wave per issuing stage")
 
 
 def no_reads(s):
-  def f(t):
-    t = t.replace('read_frags(af1, bf1, p, s, gs, 1);', '')
-    return re.sub(r'read_frags\(af0, bf0, last_of_pass[^;]*;', '', t, flags=re.S)
-  return in_loop(s, f)
+  for a in ("      read_b(bf1, SLOT{}, I1{});\n",
+            "      read_a(af1, NARROW ? naddr(s, 1, cur_off) : aaddr[(s * KS + 1) % TPP]);\n",
+            "        read_b(bf0, SLOT1{}, I0{});\n",
+            "        read_a(af0, NARROW ? naddr(s + 1, 0, cur_off) : aaddr[((s + 1) * KS) % TPP]);\n",
+            "        read_b(bf0, I0{}, I0{});\n",
+            "        read_a(af0, next_narrow ? naddr(0, 0, cur_off + delta) : aaddr[0] + delta);\n"):
+    assert a in s, a
+    s = s.replace(a, '')
+  return s
 
 
-def no_mfma(s):
-  def f(t):
-    t = t.replace('mfma_step(af0, bf0);', 'acc[0][0][0] += af0[0][0] + bf0[0][0];')
-    t = t.replace('mfma_step(af1, bf1);', 'acc[0][0][1] += af1[0][0] + bf1[0][0];')
-    return t
-  return in_loop(s, f)
+def no_barrier(s):
+  a = "      __builtin_amdgcn_s_barrier();\n      // ---- second half"
+  assert a in s
+  return s.replace(a, "      // ---- second half")
 
 
 def no_epilogue(s):
@@ -68,13 +59,12 @@ def no_epilogue(s):
 
 VARIANTS = {
     'base': lambda s: s,
-    'novm': no_vmwait,
-    'nobar': lambda s: no_barrier(no_vmwait(s)),
+    'noepi': no_epilogue,
+    'noloop': no_loop,
     'nodma': no_dma,
     'noreads': no_reads,
-    'nomfma': no_mfma,
-    'noepi': no_epilogue,
-    'loop': lambda s: no_epilogue(no_barrier(no_dma(s))),
+    'nobar': no_barrier,
+    'mfmaonly': lambda s: no_barrier(no_reads(no_dma(s))),
 }
 
 
