@@ -57,6 +57,15 @@ def no_epilogue(s):
       '    return;\n  }\n', 1)
 
 
+def stagger(kind, n):
+  def f(s):
+    a = "  const int lin = blockIdx.x;\n"
+    assert a in s
+    cond = {'slot': "((lin >> 3) >> 5) & 1", 'adj': "(lin >> 3) & 1"}[kind]
+    return s.replace(a, a + "  if (lin < 512 && (%s)) {\n    for (int i = 0; i < %d; ++i) __builtin_amdgcn_s_sleep(127);\n  }\n" % (cond, n))
+  return f
+
+
 VARIANTS = {
     'base': lambda s: s,
     'noepi': no_epilogue,
@@ -65,6 +74,10 @@ VARIANTS = {
     'noreads': no_reads,
     'nobar': no_barrier,
     'mfmaonly': lambda s: no_barrier(no_reads(no_dma(s))),
+    'stag_slot2': stagger('slot', 2),
+    'stag_slot4': stagger('slot', 4),
+    'stag_adj2': stagger('adj', 2),
+    'stag_adj4': stagger('adj', 4),
 }
 
 

@@ -10,20 +10,22 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/traffic_$c -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_kernel_timing > gpurun_out/traffic_$c.log 2>&1
 done
 python3 - <<'PY'
-import csv, glob, collections, json
+import csv, glob, collections, json, os
 res = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-    for f in glob.glob('gpurun_out/traffic_%s/*/*counter_collection.csv' % c):
-        for r in csv.DictReader(open(f)):
-            n = r['Kernel_Name']
-            fam = ('swconv' if ('swconv_kernel' in n or 'swconv_swp_kernel' in n) else
-                   'wgrad_reduce' if 'wgrad_reduce' in n else
-                   'wgrad' if 'wgrad_' in n else None)
-            if fam is None or r['Counter_Name'] != c:
-                continue
-            a = res[fam][c]
-            a[0] += 1
-            a[1] += float(r['Counter_Value'])
+    # (the newest run only: gpurun_out/ may hold earlier passes)
+    fs = sorted(glob.glob('gpurun_out/traffic_%s/*/*counter_collection.csv' % c), key=os.path.getmtime)
+    for r in csv.DictReader(open(fs[-1])):
+        n = r['Kernel_Name']
+        fam = ('swconv' if ('swconv_kernel' in n or 'swconv_swp_kernel' in n) else
+               'wgrad_reduce' if 'wgrad_reduce' in n else
+               'wgrad_batched' if 'wgrad_multi' in n else
+               'wgrad_single' if ('wgrad_kernel' in n and 'dense1' not in n) else None)
+        if fam is None or r['Counter_Name'] != c:
+            continue
+        a = res[fam][c]
+        a[0] += 1
+        a[1] += float(r['Counter_Value'])
 out = {}
 for fam, d in res.items():
     n = d['FETCH_SIZE'][0]
@@ -34,7 +36,11 @@ for fam, d in res.items():
     # is exact for 16-B-per-lane stores and float atomics.  Units: KiB.
     out[fam] = dict(launches=n, fetch_kib_raw=fetch_kb, write_kib=write_kb,
                     hbm_bytes_per_launch=(2 * fetch_kb + write_kb) * 1024)
-import subprocess
+# cg_wgrad_batched: the conv layers of one backward pass in one launch (5 critic
+# passes at 3 x 128 samples + 1 generator pass at 128 per step); algorithmic
+# bytes = x + g of every layer once + the partial sums written
+out['wgrad_batched']['note'] = ('average over the 5 critic-pass launches (nB 384) and the generator-pass '
+                                'launch (nB 128) of a step; x + g once + partial sums: 793 / 264 MB')
 try:
     out['commit'] = open('profiles/.head_commit').read().strip()
 except OSError:
