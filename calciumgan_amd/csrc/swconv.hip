@@ -1053,6 +1053,31 @@ extern "C" int cg_tile_shape(int tile, int* rows, int* cols) {
   return 0;
 }
 
+// split-K finishing launch: y = epi(sum_z ws[z] + bias), bf16.  own_pair: the
+// launch is profiled as a family launch of its own (software-pipelined tiles);
+// else `stop` (if any) closes the event pair the main launch opened.
+static int split_finish_launch(const cg_conv_desc* d, const ConvArgs& a, hipStream_t s,
+                        bool own_pair, hipEvent_t stop) {
+  SplitFinishArgs f;
+  f.ws = d->split_ws; f.nsplit = a.ksplit; f.stride = a.split_stride;
+  f.bias = d->bias; f.mask = reinterpret_cast<const uint16_t*>(d->mask_src);
+  f.y = reinterpret_cast<uint16_t*>(d->y);
+  f.N = d->N; f.Cy = d->Cy; f.epilogue = d->epilogue; f.alpha = d->alpha;
+  f.total8 = a.split_stride / 8;
+  const long long blocks = (f.total8 + 255) / 256;
+  if (own_pair) {
+    CG_LAUNCH_PROF(CG_FAMILY_SWCONV, split_finish_kernel, dim3((unsigned)blocks),
+                   dim3(256), 0, s, f);
+  } else if (stop) {
+    hipExtLaunchKernelGGL(split_finish_kernel, dim3((unsigned)blocks), dim3(256),
+                          0, s, nullptr, stop, 0, f);
+  } else {
+    hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       s, f);
+  }
+  CG_LAUNCH_CHECK();
+}
+
 static int swconv_run(const cg_conv_desc* d, void* stream);
 
 extern "C" int cg_swconv(const cg_conv_desc* d, void* stream) {
@@ -1168,8 +1193,11 @@ static int swconv_run(const cg_conv_desc* d, void* stream) {
     a.gm = (a.M + TM - 1) / TM;
     a.gn = (d->N + TN - 1) / TN;
     a.gp = d->nphase;
-    return swconv_swp_launch(a, R, tc.swp_wm, tc.wgn, tc.mt, a.ksplit, g_dry_run,
-                             (hipStream_t)stream);
+    const int rc = swconv_swp_launch(a, R, tc.swp_wm, tc.wgn, tc.mt, a.ksplit,
+                                     g_dry_run, (hipStream_t)stream);
+    if (rc || a.ksplit == 1 || g_dry_run) return rc;
+    // (both launches carry their own event pair under cg_profile_enable)
+    return split_finish_launch(d, a, (hipStream_t)stream, true, nullptr);
   }
   size_t ldsA_bytes = (size_t)a.ldsA_elems * 2;
   if (ldsA_bytes < (size_t)kScratchBytes) ldsA_bytes = kScratchBytes;
@@ -1216,19 +1244,5 @@ static int swconv_run(const cg_conv_desc* d, void* stream) {
 #undef CG_DISPATCH
   g_split_prof.on = false;
   if (rc || a.ksplit == 1 || g_dry_run) return rc;
-  // split-K finishing launch: y = epi(sum_z ws[z] + bias), bf16
-  SplitFinishArgs f;
-  f.ws = d->split_ws; f.nsplit = a.ksplit; f.stride = a.split_stride;
-  f.bias = d->bias; f.mask = reinterpret_cast<const uint16_t*>(d->mask_src);
-  f.y = reinterpret_cast<uint16_t*>(d->y);
-  f.N = d->N; f.Cy = d->Cy; f.epilogue = d->epilogue; f.alpha = d->alpha;
-  f.total8 = a.split_stride / 8;
-  long long blocks = (f.total8 + 255) / 256;
-  if (split_timed)
-    hipExtLaunchKernelGGL(split_finish_kernel, dim3((unsigned)blocks), dim3(256),
-                          0, s, nullptr, split_stop, 0, f);
-  else
-    hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       s, f);
-  CG_LAUNCH_CHECK();
+  return split_finish_launch(d, a, s, false, split_timed ? split_stop : nullptr);
 }

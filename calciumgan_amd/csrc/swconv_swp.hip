@@ -117,6 +117,11 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   const int y_off = a.y_off + phase * a.yoff_phase_step;
   const int m0 = bm * TM;
   const int n0 = bn * TN;
+  // split-K: this workgroup walks channel chunks [chunk0, chunk0 + nchunks) and
+  // leaves f32 partial sums in its slice of the workspace (a.y; the host set
+  // out_f32 and no epilogue: cg_swconv's finishing launch applies them)
+  const int zsplit = a.ksplit > 1 ? (int)blockIdx.y : 0;
+  const int chunk0 = zsplit * a.nchunks;
   const int b0 = m0 / a.Lu;               // first sample of the tile
   const int u00 = m0 - b0 * a.Lu;         // its first output row (nseg == 1)
 
@@ -175,13 +180,13 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     if (p < full_passes) {
       const int cc = R == 2 ? (p >> 1) : p;
       o = (R == 2 && (p & 1)) ? o1 : o0;
-      add = cc * 64;
+      add = (chunk0 + cc) * 64;
     } else {
       // narrow last chunk: chunk q of a row = the first 8-channel group of
       // source-row parity q (q < 2; the rest of the row is never read)
       const uint32_t sel = (q & 1) ? o1 : o0;
       o = (q >= 2 || sel == ~0u) ? ~0u : sel - q * 16;
-      add = (a.nchunks - 1) * 64;
+      add = (chunk0 + a.nchunks - 1) * 64;
     }
     // (opaque to LICM: hoisted out of the stage loop, the offsets of all slots
     // would sit in registers for a whole pass)
@@ -231,7 +236,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     boff[i] = (row * a.Kpack + c * 8) * 2;
   }
   // (one running scalar offset: + one 64-deep stage per issue)
-  int bstage = 0;
+  int bstage = chunk0 * a.Fp * 16;
   auto issue_b = [&](int slot_idx) {
     uint16_t* slot = ldsB + slot_idx * kBufB;
 #pragma unroll
@@ -607,7 +612,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
           for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
         }
         if (a.out_f32) {
-          float* dst = reinterpret_cast<float*>(a.y) + rowoff;
+          float* dst = reinterpret_cast<float*>(a.y) + zsplit * a.split_stride + rowoff;
           *reinterpret_cast<f32x4*>(dst + nA) = f32x4{v[0], v[1], v[2], v[3]};
           if (okB)
             *reinterpret_cast<f32x4*>(dst + nB) = f32x4{v[4], v[5], v[6], v[7]};
@@ -668,7 +673,10 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
                       int ksplit, bool dry, hipStream_t stream) {
   // uniform 32-channel K walk, one tap per K-step; no split-K (the tile
   // kernels keep that); the fused LayerNorm needs whole rows in the workgroup
-  if (a.CK != 32 || a.taps % stride || ksplit > 1) return CG_EINVAL;
+  if (a.CK != 32 || a.taps % stride) return CG_EINVAL;
+  // split-K (blockIdx.y walks its share of the channel chunks, f32 partial sums
+  // into the caller's workspace): whole chunks only
+  if (ksplit > 1 && (a.narrow || a.epilogue == CG_EPI_LN_LRELU)) return CG_EINVAL;
   const bool ln = a.epilogue == CG_EPI_LN_LRELU;
   if (ln && (wn != 2 || stride != 1 || a.N > 128)) return CG_EINVAL;
   if (stride == 2 && !a.pmajor) return CG_EINVAL;
@@ -704,7 +712,8 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   const size_t epi = (size_t)nw * 16 * kSwpScrPitch * 4 + nw * 16 * 2 * 4 + 256 * 4 + 64;
   if (lds < epi) lds = epi;
   if (lds > 160 * 1024) return CG_EINVAL;
-  dim3 grid((unsigned)(((a.gm + 7) / 8) * 8 * a.gn * a.gp));
+  dim3 grid((unsigned)(((a.gm + 7) / 8) * 8 * a.gn * a.gp),
+            (unsigned)(ksplit > 1 ? ksplit : 1));
   if (ln) {
     if (wm == 4 && mt == 4) return launch_swp<1, 4, 2, 4, true>(pa, grid, lds, dry, stream);
     if (wm == 2 && mt == 4) return launch_swp<1, 2, 2, 4, true>(pa, grid, lds, dry, stream);

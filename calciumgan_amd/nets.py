@@ -410,6 +410,9 @@ def _autotune_tile(d):
       nch = d.Cx // d.CK
       cands += [(small, ks, sp, z) for small, ks, sp, _ in list(cands)
                 for z in (2, 4) if nch % z == 0]
+      if not d.w_narrow_last:
+        swp += [(small, ks, sp, z) for small, ks, sp, _ in list(swp)
+                for z in (2, 4) if nch % z == 0]
     cands += swp
     times = {}
     y_saved = d.y

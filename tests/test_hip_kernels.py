@@ -152,16 +152,18 @@ def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp):
 
 
 @pytest.mark.parametrize('ksplit', [2, 4])
-@pytest.mark.parametrize('tile', [0, 1, 2, 4, 8])
+@pytest.mark.parametrize('tile', [0, 1, 2, 4, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize('nB,L,Ci,Co,k,epi', [(3, 256, 128, 192, 24, 1),
                                               (2, 128, 102, 64, 24, 2),
-                                              (4, 64, 256, 320, 24, 0)])
+                                              (4, 64, 256, 320, 24, 0),
+                                              (2, 512, 256, 128, 24, 2)])
 def test_conv_fwd_split_k(tile, ksplit, nB, L, Ci, Co, k, epi):
   """cg_conv_desc.ksplit: several workgroups per output tile, each over a share
   of the channel chunks, f32 partial sums + a finishing launch (bias /
   LeakyReLU / in-place mask).  Exact on integer data, so identical to the
   unsplit launch and to the oracle; includes the narrow last chunk (Ci = 102),
-  which only the last split walks."""
+  which only the last split walks (tile kernels; the software-pipelined tiles
+  9-12 split whole chunks only and answer CG_EINVAL there)."""
   rng = np.random.RandomState(12)
   x = H.int_tensor(rng, (nB, L, Ci))
   W = H.int_tensor(rng, (k, Ci, Co), -2, 2, 0.5)
