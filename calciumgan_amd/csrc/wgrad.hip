@@ -342,10 +342,6 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
   // + exec-masked branches per piece, was 3/4 of the staging cost.)  Interior
   // tiles (no padding, no reflection in the window) use `pre` as it is; edge
   // tiles recompute the row, branch-free.
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t*>(a.x), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t*>(a.g), 0, 0x7fffffff, 0x00020000);
   auto dma = [&](const __amdgpu_buffer_rsrc_t& r, int soff, int piece, unsigned vo,
                  unsigned so) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -376,9 +372,17 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
     // no window row (of the WRP staged per parity) is padding or reflected
     const bool interior = srow0 + (sft < 0 ? sft : 0) >= 0 &&
                           srow0 + 2 * G::WRP - 1 + (sft > 0 ? sft : 0) < a.Lx;
-    const unsigned xsample = (unsigned)b * (unsigned)(a.Lx * rowb);
+    // descriptors based at the tile's sample / first g row (4 scalar moves per
+    // tile): offsets stay 32-bit whatever the batch size
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(a.x + (long long)b * a.Lx * a.Cx), 0, 0x7fffffff,
+        0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(a.g + ((long long)b * a.Lu + u0) * a.Cg), 0,
+        0x7fffffff, 0x00020000);
+    const unsigned xsample = 0u;
     if (interior) {
-      const unsigned xs = xsample + (unsigned)((srow0 + sft) * rowb);
+      const unsigned xs = (unsigned)((srow0 + sft) * rowb);
 #pragma unroll
       for (int k = 0; k < NXF; ++k) dma(rx, soff, k * 8 + wave, (unsigned)pre[k], xs);
       if (NXT && wave < NXT) dma(rx, soff, NXF * 8 + wave, (unsigned)pre[NXF], xs);
@@ -399,7 +403,7 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
       for (int k = 0; k < NXF; ++k) dma(rx, soff, k * 8 + wave, edge(k), xsample);
       if (NXT && wave < NXT) dma(rx, soff, NXF * 8 + wave, edge(NXF), xsample);
     }
-    const unsigned gs = (unsigned)(b * a.Lu + u0) * (unsigned)(a.Cg * 2);
+    const unsigned gs = 0u;
 #pragma unroll
     for (int k = 0; k < NGF; ++k) dma(rg, soff, G::NPX + k * 8 + wave, (unsigned)og[k], gs);
   };
@@ -994,8 +998,7 @@ int plan_wgrad(const cg_wgrad_desc* d, WgradPlan& p) {
   a.ring = 0;
   p.ring_lds = 0;
   if (!rowsplit && p.pipe && d->taps == 24 && !d->classic_staging &&
-      (long long)d->nB * d->Lx * d->Cx * 2 < (1ll << 31) &&
-      (long long)d->nB * d->Lu * d->Cg * 2 < (1ll << 31) &&
+      (long long)d->Lx * d->Cx * 2 < (1ll << 31) &&
       (!d->shifts || (d->nB + d->seg_size - 1) / d->seg_size <= 64)) {
     a.ring = 1;
     p.ring_lds = TT == 128 ? 4 * RingGeom<128>::STAGE : 4 * RingGeom<64>::STAGE;
