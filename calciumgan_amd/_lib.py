@@ -23,7 +23,8 @@ TILES = {0: (256, 64, 16), 1: (64, 64, 16), 2: (128, 64, 16),
          6: (128, 128, 32), 7: (256, 128, 16),
          8: (128, 128, 16)}
 # CG_TILE_SWP_*: value -> (rows, cols); swconv_swp.hip, two waves per SIMD
-SWP_TILES = {9: (512, 64), 10: (256, 64), 11: (256, 128), 12: (128, 128)}
+SWP_TILES = {9: (512, 64), 10: (256, 64), 11: (256, 128), 12: (128, 128),
+             13: (128, 64)}
 
 
 def tile_shape(tile):

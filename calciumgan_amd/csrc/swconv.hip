@@ -1043,6 +1043,7 @@ static const TileCfg kTileCfgs[CG_NUM_TILES] = {
     {16, 1, 4, 4},  // CG_TILE_SWP_256x64
     {16, 2, 4, 4},  // CG_TILE_SWP_256x128
     {16, 2, 4, 2},  // CG_TILE_SWP_128x128
+    {16, 1, 2, 4},  // CG_TILE_SWP_128x64
 };
 
 extern "C" int cg_tile_shape(int tile, int* rows, int* cols) {

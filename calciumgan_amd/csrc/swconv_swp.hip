@@ -727,6 +727,7 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   CG_SWP_R(4, 1, 4)   // 256 x 64, 4 waves
   CG_SWP_R(4, 2, 4)   // 256 x 128, 8 waves
   CG_SWP_R(2, 2, 4)   // 128 x 128, 4 waves
+  CG_SWP_R(4, 1, 2)   // 128 x 64, 4 waves
 #undef CG_SWP_R
 #undef CG_SWP
   return CG_EINVAL;

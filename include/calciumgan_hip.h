@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 12
+#define CG_ABI_VERSION 13
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -53,13 +53,15 @@ extern "C" {
  * workgroup or two 4-wave workgroups per CU), fragments double-buffered in
  * registers at K-step granularity, the source window and the weight ring both
  * filled by LDS-DMA.  v_mfma_f32_16x16x32, CK == 32, at least six taps per
- * source-row parity; no split-K; the LayerNorm epilogue on the 128-column tiles.
+ * source-row parity; split-K over whole channel chunks; the LayerNorm epilogue
+ * on the 128-column tiles.
  * Same results as the tiles above. */
 #define CG_TILE_SWP_512x64 9
 #define CG_TILE_SWP_256x64 10
 #define CG_TILE_SWP_256x128 11
 #define CG_TILE_SWP_128x128 12
-#define CG_NUM_TILES 13
+#define CG_TILE_SWP_128x64 13  /* 4 waves x (32 x 64): short launches (more workgroups) */
+#define CG_NUM_TILES 14
 
 int cg_abi_version(void);
 /* Storage type of activations / activation gradients / packed operands this

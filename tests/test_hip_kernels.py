@@ -152,7 +152,7 @@ def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp):
 
 
 @pytest.mark.parametrize('ksplit', [2, 4])
-@pytest.mark.parametrize('tile', [0, 1, 2, 4, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize('tile', [0, 1, 2, 4, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize('nB,L,Ci,Co,k,epi', [(3, 256, 128, 192, 24, 1),
                                               (2, 128, 102, 64, 24, 2),
                                               (4, 64, 256, 320, 24, 0),
