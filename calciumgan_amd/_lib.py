@@ -24,7 +24,7 @@ TILES = {0: (256, 64, 16), 1: (64, 64, 16), 2: (128, 64, 16),
          8: (128, 128, 16)}
 # CG_TILE_SWP_*: value -> (rows, cols); swconv_swp.hip, two waves per SIMD
 SWP_TILES = {9: (512, 64), 10: (256, 64), 11: (256, 128), 12: (128, 128),
-             13: (128, 64)}
+             13: (128, 64), 14: (256, 64), 15: (128, 128)}
 
 
 def tile_shape(tile):

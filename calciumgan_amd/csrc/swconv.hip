@@ -1044,6 +1044,8 @@ static const TileCfg kTileCfgs[CG_NUM_TILES] = {
     {16, 2, 4, 4},  // CG_TILE_SWP_256x128
     {16, 2, 4, 2},  // CG_TILE_SWP_128x128
     {16, 1, 2, 4},  // CG_TILE_SWP_128x64
+    {16, 1, 2, 8},  // CG_TILE_SWP_256x64_W8
+    {16, 2, 2, 4},  // CG_TILE_SWP_128x128_W8
 };
 
 extern "C" int cg_tile_shape(int tile, int* rows, int* cols) {

@@ -261,9 +261,14 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   }
   // (absolute LDS byte addresses: the reads are inline assembly)
   const int lds0 = (int)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  int aaddr[TPP];
+  // (tap t + 8 sits 512 B behind tap t -- the swizzle only looks at address bits
+  // 5 and 8 --, so eight registers serve the twelve taps of a pass: the last
+  // four read through tap t - 8's base + 512 in the offset field)
+  static_assert(TPP <= 16, "taps 8.. of a pass reuse the bases of taps 0..");
+  constexpr int NAA = TPP < 8 ? TPP : 8;
+  int aaddr[NAA];
 #pragma unroll
-  for (int t = 0; t < TPP; ++t) aaddr[t] = lds0 + sw64(rowb0 + t * 64);
+  for (int t = 0; t < NAA; ++t) aaddr[t] = lds0 + sw64(rowb0 + t * 64);
   // narrow chunk: stage s -> parity s >> 1, K-step (s & 1) * 2 + ks; its four
   // k-groups are four consecutive taps of that parity over the same 8 channels
   // (chunk slot = parity); taps past taps/2 carry zero weights (row clamped: LDS
@@ -290,11 +295,13 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
           bf[decltype(nt)::value], vboff[KSI]);
     });
   };
-  auto read_a = [&](act8(&af)[MT], int addr) {
+  auto read_a = [&](act8(&af)[MT], int addr, auto extra_tag) {
     static_for<MT>([&](auto mt) {
-      lds_read128<decltype(mt)::value * 1024>(af[decltype(mt)::value], addr);
+      lds_read128<decltype(mt)::value * 1024 + decltype(extra_tag)::value>(
+          af[decltype(mt)::value], addr);
     });
   };
+  using X0 = std::integral_constant<int, 0>;
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -334,7 +341,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   __builtin_amdgcn_s_barrier();
   act8 af0[MT], bf0[NT], af1[MT], bf1[NT];
   read_b(bf0, I0{}, I0{});
-  read_a(af0, full_passes > 0 ? aaddr[0] : naddr(0, 0, 0));
+  read_a(af0, full_passes > 0 ? aaddr[0] : naddr(0, 0, 0), X0{});
   lds_wait();
 
   // One pass, NSTG stages unrolled.  aaddr[] points into the window buffer of
@@ -359,7 +366,13 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       using SLOT1 = integral_constant<int, (s + 1) % kSwpRing>;
       // ---- first half -------------------------------------------------------
       read_b(bf1, SLOT{}, I1{});
-      read_a(af1, NARROW ? naddr(s, 1, cur_off) : aaddr[(s * KS + 1) % TPP]);
+      {
+        constexpr int T = (s * KS + 1) % TPP;
+        if constexpr (NARROW)
+          read_a(af1, naddr(s, 1, cur_off), X0{});
+        else
+          read_a(af1, aaddr[T % NAA], integral_constant<int, (T / NAA) * 512>{});
+      }
       mfma_step(af0, bf0);
       lds_wait();
       // ---- stage boundary ---------------------------------------------------
@@ -373,12 +386,16 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       // ---- second half ------------------------------------------------------
       if constexpr (s + 1 < NSTG) {
         read_b(bf0, SLOT1{}, I0{});
-        read_a(af0, NARROW ? naddr(s + 1, 0, cur_off) : aaddr[((s + 1) * KS) % TPP]);
+        constexpr int T = ((s + 1) * KS) % TPP;
+        if constexpr (NARROW)
+          read_a(af0, naddr(s + 1, 0, cur_off), X0{});
+        else
+          read_a(af0, aaddr[T % NAA], integral_constant<int, (T / NAA) * 512>{});
       } else {
         // first K-step of the next pass (other window buffer, ring slot 0);
         // after the last pass a harmless read of resident LDS
         read_b(bf0, I0{}, I0{});
-        read_a(af0, next_narrow ? naddr(0, 0, cur_off + delta) : aaddr[0] + delta);
+        read_a(af0, next_narrow ? naddr(0, 0, cur_off + delta) : aaddr[0] + delta, X0{});
       }
       // (the DMA issue sits behind the reads: in front of them the LDS pipe and
       // the matrix pipe both idle while the wave builds addresses)
@@ -402,7 +419,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       lds_wait();
     });
 #pragma unroll
-    for (int t = 0; t < TPP; ++t) aaddr[t] += delta;
+    for (int t = 0; t < NAA; ++t) aaddr[t] += delta;
   };
   using False = integral_constant<bool, false>;
   using True = integral_constant<bool, true>;
@@ -646,8 +663,11 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
 
 // (the body is a __device__ function: with the buffer-resource builtins written
 // directly in a __global__ template the host pass emits no stub for it)
+// (second launch bound = waves per SIMD the register budget must allow: the
+// 32-row wave tiles run 3 four-wave or 2 eight-wave workgroups per CU)
 template <int R, int WM, int WN, int MT, bool LN = false>
-__global__ __launch_bounds__(WM* WN * 64, 2) void swconv_swp_kernel(SwpArgs pa) {
+__global__ __launch_bounds__(WM* WN * 64, MT == 2 ? (WM * WN == 8 ? 4 : 3) : 2) void
+swconv_swp_kernel(SwpArgs pa) {
   swconv_swp_body<R, WM, WN, MT, LN>(pa);
 }
 
@@ -717,6 +737,7 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   if (ln) {
     if (wm == 4 && mt == 4) return launch_swp<1, 4, 2, 4, true>(pa, grid, lds, dry, stream);
     if (wm == 2 && mt == 4) return launch_swp<1, 2, 2, 4, true>(pa, grid, lds, dry, stream);
+    if (wm == 4 && mt == 2) return launch_swp<1, 4, 2, 2, true>(pa, grid, lds, dry, stream);
     return CG_EINVAL;
   }
 #define CG_SWP(RR, WM, WN, MM)                                  \
@@ -728,6 +749,8 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   CG_SWP_R(4, 2, 4)   // 256 x 128, 8 waves
   CG_SWP_R(2, 2, 4)   // 128 x 128, 4 waves
   CG_SWP_R(4, 1, 2)   // 128 x 64, 4 waves
+  CG_SWP_R(8, 1, 2)   // 256 x 64, 8 waves
+  CG_SWP_R(4, 2, 2)   // 128 x 128, 8 waves
 #undef CG_SWP_R
 #undef CG_SWP
   return CG_EINVAL;

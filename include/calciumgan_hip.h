@@ -61,7 +61,9 @@ extern "C" {
 #define CG_TILE_SWP_256x128 11
 #define CG_TILE_SWP_128x128 12
 #define CG_TILE_SWP_128x64 13  /* 4 waves x (32 x 64): short launches (more workgroups) */
-#define CG_NUM_TILES 14
+#define CG_TILE_SWP_256x64_W8 14  /* 8 waves x (32 x 64): two workgroups = 4 waves per SIMD */
+#define CG_TILE_SWP_128x128_W8 15 /* 8 waves x (32 x 64), 4 x 2: the same for 128 columns */
+#define CG_NUM_TILES 16
 
 int cg_abi_version(void);
 /* Storage type of activations / activation gradients / packed operands this

@@ -152,7 +152,7 @@ def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp):
 
 
 @pytest.mark.parametrize('ksplit', [2, 4])
-@pytest.mark.parametrize('tile', [0, 1, 2, 4, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize('tile', [0, 1, 2, 4, 8, 9, 10, 11, 12, 13, 14, 15])
 @pytest.mark.parametrize('nB,L,Ci,Co,k,epi', [(3, 256, 128, 192, 24, 1),
                                               (2, 128, 102, 64, 24, 2),
                                               (4, 64, 256, 320, 24, 0),
@@ -312,7 +312,7 @@ def test_conv_transpose_fwd_bitexact(B, L, Ci, Co, k):
 
 
 @pytest.mark.parametrize('tile,ks', [(5, 2), (5, 4), (6, 2), (6, 4), (7, 2),
-                                     (7, 4), (8, 2), (8, 4), (11, 2), (12, 2)])
+                                     (7, 4), (8, 2), (8, 4), (11, 2), (12, 2), (15, 2)])
 @pytest.mark.parametrize('B,L,Ci,Co,k', [(3, 256, 128, 102, 24),
                                           (2, 512, 192, 128, 24),
                                           (5, 16, 64, 40, 24),
