@@ -30,16 +30,10 @@ def no_dma(s):  # no DMA issue inside the passes (stale LDS is read)
   return s.replace(b, "        if (false) {\n          // apw (1 or 2) slots of this wave per issuing stage")
 
 
-def no_reads(s):
-  for a in ("      read_b(bf1, SLOT{}, I1{});\n",
-            "      read_a(af1, NARROW ? naddr(s, 1, cur_off) : aaddr[(s * KS + 1) % TPP]);\n",
-            "        read_b(bf0, SLOT1{}, I0{});\n",
-            "        read_a(af0, NARROW ? naddr(s + 1, 0, cur_off) : aaddr[((s + 1) * KS) % TPP]);\n",
-            "        read_b(bf0, I0{}, I0{});\n",
-            "        read_a(af0, next_narrow ? naddr(0, 0, cur_off + delta) : aaddr[0] + delta);\n"):
-    assert a in s, a
-    s = s.replace(a, '')
-  return s
+def no_reads(s):  # no fragment reads at all (uninitialised operands)
+  n = len(re.findall(r'lds_read128<[^;]*;', s))
+  assert n == 2, n
+  return re.sub(r'lds_read128<[^;]*;', ';', s)
 
 
 def no_barrier(s):
@@ -66,6 +60,13 @@ def stagger(kind, n):
   return f
 
 
+def setprio(s):  # MFMA blocks at priority 1 (the reads / DMA issue of the other waves yield)
+  for a in ("      mfma_step(af0, bf0);\n", "      mfma_step(af1, bf1);\n"):
+    assert a in s
+    s = s.replace(a, "      __builtin_amdgcn_s_setprio(1);\n" + a + "      __builtin_amdgcn_s_setprio(0);\n")
+  return s
+
+
 VARIANTS = {
     'base': lambda s: s,
     'noepi': no_epilogue,
@@ -74,6 +75,7 @@ VARIANTS = {
     'noreads': no_reads,
     'nobar': no_barrier,
     'mfmaonly': lambda s: no_barrier(no_reads(no_dma(s))),
+    'setprio': setprio,
     'stag_slot2': stagger('slot', 2),
     'stag_slot4': stagger('slot', 4),
     'stag_adj2': stagger('adj', 2),
