@@ -362,9 +362,14 @@ def _autotune_tile(d):
         _TILE_CACHE[key] = best
       return _apply_tile_choice(d, best)
   if best is None and not _AUTOTUNE:
+    # no timing: the software-pipelined tile that wins most geometries when it
+    # is tuned (8 waves of 32 x 64 wave tiles; the 128-column form for the
+    # fused LayerNorm), if the library admits it for this launch; else the
+    # static tile-kernel choice stays
+    best = _static_swp_choice(d)
     if multi:
-      parallel.broadcast_object(None)
-    return
+      parallel.broadcast_object(best)
+    return _apply_tile_choice(d, best)
   if best is None:
     lib = _lib.load()
     st = _stream()
@@ -456,6 +461,22 @@ def _autotune_tile(d):
   if multi:
     parallel.broadcast_object(best)
   _apply_tile_choice(d, best)
+
+
+def _static_swp_choice(d):
+  if not _SWP_TILES or d.CK != 32:
+    return None
+  order = (15, 12) if d.epilogue == _lib.EPI_LN_LRELU else (14, 13, 10)
+  lib = _lib.load()
+  saved = (d.tile, d.stage_ksteps, d.split_parity, d.ksplit)
+  pick = None
+  for tile in order:
+    d.tile, d.stage_ksteps, d.split_parity, d.ksplit = tile, 2, 0, 0
+    if lib.cg_swconv_check(ctypes.byref(d)) == 0:
+      pick = (tile, 2, 0, 1)
+      break
+  d.tile, d.stage_ksteps, d.split_parity, d.ksplit = saved
+  return pick
 
 
 def _apply_tile_choice(d, best):
