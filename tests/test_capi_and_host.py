@@ -75,6 +75,60 @@ def test_tile_table_matches_library():
   assert lib.cg_tile_shape(len(tiles), None, None) == _lib.CG_EINVAL
 
 
+def _dry_conv_desc(stride, taps, nB, Lx, Cx, N, tile, epilogue=0):
+  """A descriptor for cg_swconv_check only (no pointer is dereferenced)."""
+  import ctypes
+  d = _lib.ConvDesc()
+  d.x = d.w = d.y = 0x1000
+  d.nB, d.Lx, d.Cx, d.seg_size = nB, Lx, Cx, nB
+  d.taps, d.stride = taps, stride
+  d.Lu = Lx // 2 if stride == 2 else Lx
+  d.off = -geo.same_padding_left(taps, 2) if stride == 2 else -(taps // 2 - 1)
+  d.N = N
+  d.nphase = 1 if stride == 2 else 2
+  d.Ly, d.Cy = d.Lu * d.nphase, geo.pitch(N)
+  d.y_stride, d.y_off, d.CK = d.nphase, 0, 32
+  d.epilogue, d.alpha = epilogue, 0.3
+  if epilogue == _lib.EPI_LN_LRELU:
+    d.ln_gamma = d.ln_beta = d.ln_h = d.ln_mean = d.ln_rstd = 0x1000
+    d.ln_eps = 1e-3
+  d.w_phase_stride, d.off_phase_step, d.yoff_phase_step = 1 << 20, 1, 1
+  d.tile, d.stage_ksteps = tile, 2
+  d.w_parity_major = int(stride == 2)
+  return d, ctypes.byref(d)
+
+
+def test_swconv_check_admits_the_software_pipelined_tiles():
+  """cg_swconv_check (the dry run nets.py validates tile choices with) on the
+  CPU: the 32-row wave tiles are admitted at the cfg2 layer shapes and refused
+  where a pass is not 12 taps or a wave's rows would straddle samples."""
+  lib = _lib.load()
+  ok = lambda *a, **k: lib.cg_swconv_check(_dry_conv_desc(*a, **k)[1])
+  for tile in (13, 14, 15):
+    assert ok(2, 24, 384, 2048, 128, 192, tile) == 0      # critic forward
+    assert ok(1, 12, 128, 128, 320, 256, tile) == 0       # input gradient / convT
+  assert ok(1, 12, 640, 1024, 128, 102, 15, epilogue=_lib.EPI_LN_LRELU) == 0
+  assert ok(1, 12, 640, 1024, 128, 102, 14, epilogue=_lib.EPI_LN_LRELU) == _lib.CG_EINVAL
+  assert ok(1, 12, 640, 256, 256, 192, 15, epilogue=_lib.EPI_LN_LRELU) == _lib.CG_EINVAL
+  assert ok(2, 8, 4, 256, 64, 64, 14) == _lib.CG_EINVAL      # 4 taps per parity
+  assert ok(2, 24, 4, 32, 64, 64, 14) == _lib.CG_EINVAL      # 16-row samples
+  rows, cols = ctypes_int(), ctypes_int()
+  for tile, shape in _lib.SWP_TILES.items():
+    assert lib.cg_tile_shape(tile, rows.ref, cols.ref) == 0
+    assert (rows.value, cols.value) == shape
+
+
+class ctypes_int(object):
+  def __init__(self):
+    import ctypes
+    self._v = ctypes.c_int(0)
+    self.ref = ctypes.byref(self._v)
+
+  @property
+  def value(self):
+    return self._v.value
+
+
 def test_no_cpu_fallback_without_device():
   if torch.cuda.is_available():
     pytest.skip('device present')
