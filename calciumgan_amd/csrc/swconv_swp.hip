@@ -691,8 +691,8 @@ int launch_swp(const SwpArgs& pa, dim3 grid, size_t lds, bool dry, hipStream_t s
 
 int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
                       int ksplit, bool dry, hipStream_t stream) {
-  // uniform 32-channel K walk, one tap per K-step; no split-K (the tile
-  // kernels keep that); the fused LayerNorm needs whole rows in the workgroup
+  // uniform 32-channel K walk, one tap per K-step; the fused LayerNorm needs
+  // whole rows in the workgroup
   if (a.CK != 32 || a.taps % stride) return CG_EINVAL;
   // split-K (blockIdx.y walks its share of the channel chunks, f32 partial sums
   // into the caller's workspace): whole chunks only
