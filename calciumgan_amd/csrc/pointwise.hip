@@ -503,6 +503,14 @@ __global__ __launch_bounds__(kThreads) void sumsq_kernel(
     atomicAdd(sumsq + b, part[0] + part[1] + part[2] + part[3]);
 }
 
+// (a kernel, not hipMemsetAsync: a memset NODE of a captured hipGraph wrote a
+// stale non-zero pattern when other work ran between two replays -- the
+// round-2 "stale graph" penalties of 1e25; tools/probe/graph_memset.hip)
+__global__ void zero_f32_kernel(float* v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = 0.f;
+}
+
 __global__ void sqrt_kernel(float* v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = sqrtf(v[i]);
@@ -999,8 +1007,8 @@ extern "C" int cg_cast_pad(const float* src, void* dst, long long rows, int C,
 extern "C" int cg_rownorm(const void* g, float* norm, int B, long long n,
                           void* stream) {
   if (n % 8 || B < 1) return CG_EINVAL;
-  hipError_t e = hipMemsetAsync(norm, 0, sizeof(float) * B, S_(stream));
-  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((B + 255) / 256), dim3(256), 0,
+                     S_(stream), norm, B);
   int chunks = (int)((n / 8 + kThreads - 1) / kThreads);
   if (chunks > 64) chunks = 64;
   hipLaunchKernelGGL(sumsq_kernel, dim3(chunks, B), dim3(kThreads), 0,

@@ -47,10 +47,10 @@ struct SwpArgs {
   int nst;           // weight stages per full pass (tpp / 2)
   int total_stages;
   int npad_rows;     // rows of the packed operand (N rounded up to 128)
+  int ntl;           // linear tile ids: gm rounded up to 8, x gn x gp
   float inv_WRs;
 };
 
-constexpr int kSwpScrPitch = 68;  // f32 epilogue scratch pitch
 constexpr int kSwpRing = 3;       // weight ring depth
 constexpr int kSwpTapsPerPass = 12;  // 24-tap stride-2 / 12-tap stride-1 windows
 
@@ -62,9 +62,10 @@ __device__ __forceinline__ int sw64(int byte) {
 
 // R: source stride.  WM x WN waves (4 or 8); wave tile (16 * MT) x 64.
 // LN: CG_EPI_LN_LRELU (LayerNorm + LeakyReLU in the epilogue; 128-column tiles).
-template <int R, int WM, int WN, int MT, bool LN>
+template <int R, int WM, int WN, int MT, bool LN, bool NRW>
 __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   static_assert(WM * WN == 4 || WM * WN == 8, "one or two waves per SIMD");
+  static_assert(!NRW || R == 2, "narrow last chunks exist for stride 2 only");
   static_assert(!LN || WN == 2, "the fused LayerNorm needs a 128-column tile");
   const ConvArgs& a = pa.c;
   constexpr int NW = WM * WN;
@@ -90,7 +91,20 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsA = smem;
   uint16_t* ldsB = reinterpret_cast<uint16_t*>(smem + 2 * ABYTES);
+  // behind the ring: phase shifts of the tile's segments (32 ints), the
+  // rowsumsq slots of the waves (16 floats) and, for the fused LayerNorm, the
+  // row-statistics exchange table and gamma / beta.  Nothing of the epilogue
+  // lives in the window / ring area: the next tile's DMAs land there meanwhile.
   int* sh_lds = reinterpret_cast<int*>(smem + 2 * ABYTES + kSwpRing * kBufB * 2);
+  float* wsum = reinterpret_cast<float*>(sh_lds + 32);
+  float* part = wsum + 16;                // [2][NW][16][2]
+  float* lnp = part + 2 * NW * 32;        // gamma[128] | beta[128] (zero past N)
+  // the 128-register stride-2 256 x 64 tile keeps the row words of its window
+  // pieces in LDS, [piece slot][thread] (its K loop uses every register: left to
+  // the compiler, they became scratch reloads behind s_waitcnt vmcnt(0), i.e. a
+  // drain of the DMA pipeline, in the middle of a pass)
+  constexpr bool ALDS = R == 2 && NW == 8 && WN == 1 && MT == 2;
+  uint32_t* arow_lds = reinterpret_cast<uint32_t*>(wsum + 16);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -101,96 +115,151 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   const int wn = wave % WN;
   const int rM = lane & 15;
   const int g = lane >> 4;
-  // XCD-aware mapping (as swconv_kernel): the workgroups that share one row
-  // tile's source window get linear ids congruent mod 8
-  const int lin = blockIdx.x;
-  const int xcd = lin & 7;
-  const int jq = lin >> 3;
-  const int gnp = a.gn * a.gp;
-  const int np_i = jq % gnp;
-  const int bm = (jq / gnp) * 8 + xcd;
-  if (bm >= a.gm) return;
-  const int bn = np_i % a.gn;
-  const int phase = np_i / a.gn;
-  const uint16_t* __restrict__ wp = a.w + (long long)phase * a.w_phase_stride;
-  const int off = a.off + phase * a.off_phase_step;
-  const int y_off = a.y_off + phase * a.yoff_phase_step;
-  const int m0 = bm * TM;
-  const int n0 = bn * TN;
   // split-K: this workgroup walks channel chunks [chunk0, chunk0 + nchunks) and
   // leaves f32 partial sums in its slice of the workspace (a.y; the host set
   // out_f32 and no epilogue: cg_swconv's finishing launch applies them)
   const int zsplit = a.ksplit > 1 ? (int)blockIdx.y : 0;
   const int chunk0 = zsplit * a.nchunks;
-  const int b0 = m0 / a.Lu;               // first sample of the tile
-  const int u00 = m0 - b0 * a.Lu;         // its first output row (nseg == 1)
-
-  // per-sample phase shifts of the tile's segments
-  if (a.shifts != nullptr && tid < a.nseg) {
-    const int b = b0 + tid;
-    sh_lds[tid] = b < a.nB ? a.shifts[b / a.seg_size] : 0;
-  }
-  __syncthreads();
-
-  // ---- window pieces ---------------------------------------------------------
-  // piece j of the window of pass p -> buffer p & 1, bytes [j KiB, (j+1) KiB):
-  // lane L lands on (row 16 j + L/4, slot L & 3) and fetches the chunk that
-  // slot holds after the swizzle.  Wave w owns pieces j = k NW + w; the source
-  // offset of (k, source-row parity) at channel chunk 0 is computed ONCE here
-  // (the hot loop only passes the chunk offset as the scalar operand).
-  const int pslot = lane & 3;
-  const int full_passes = (a.nchunks - (a.narrow ? 1 : 0)) * R;
-  // (byte offsets from the tile's first sample; ~0 = padding: the buffer form
-  // of the DMA fetches zeros for an offset past num_records, so there is no zero
-  // page and no 64-bit select in the loop)
-  uint32_t aoff[KPW][R];
+  const int gnp = a.gn * a.gp;
+  const int full_passes = (a.nchunks - (NRW ? 1 : 0)) * R;
   // logical 16-byte chunk this lane fetches: pieces start at multiples of 16
   // rows, so row bit 2 is lane bit 4 for every piece
-  const int aq = pslot ^ (((lane >> 4) & 1) << 1);
-#pragma unroll
-  for (int k = 0; k < KPW; ++k) {
-    const int row = (k * NW + wave) * 16 + (lane >> 2);
-    const int q = aq;
-    int seg = 0;
-    if (a.nseg > 1) seg = __float2int_rz(((float)row + 0.5f) * pa.inv_WRs);
-    const int wr = row - seg * pa.WRs;
-    const int b = b0 + seg;
-    const int u0 = a.nseg > 1 ? 0 : u00;
-    const int sft = a.shifts != nullptr && seg < a.nseg ? sh_lds[seg] : 0;
-#pragma unroll
-    for (int par = 0; par < R; ++par) {
-      uint32_t o = ~0u;
-      if (row < pa.wrows && b < a.nB) {
-        int srow = R * (u0 + wr) + off + par;
-        if (srow >= 0 && srow < a.Lx) {
-          if (a.shifts) srow = shuffle_src(srow, sft, a.Lx);
-          o = (uint32_t)(((seg * a.Lx + srow) * a.Cx + q * 8) * 2);
-        }
-      }
-      aoff[k][par] = o;
+  const int aq = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+
+  if constexpr (LN) {
+    if (tid < 128) {
+      lnp[tid] = tid < a.N ? a.ln_gamma[tid] : 0.f;
+      lnp[128 + tid] = tid < a.N ? a.ln_beta[tid] : 0.f;
     }
   }
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t*>(a.x + (long long)b0 * a.Lx * a.Cx), 0, 0x7fffffff,
-      0x00020000);
-  // issue slot k of pass p (k compile-time: the offset arrays stay in registers)
-  auto issue_a_piece = [&](int p, int k, uint32_t o0, uint32_t o1, int q) {
-    uint32_t o;
-    int add;
-    if (p < full_passes) {
+
+  // ---- tile walk ---------------------------------------------------------------
+  // The workgroup is persistent: linear tile ids lin = blockIdx.x, + gridDim.x,
+  // ... (gridDim.x is a multiple of 8, so a workgroup keeps its XCD residue).
+  // XCD-aware mapping (as swconv_kernel): the workgroups that share one row
+  // tile's source window get linear ids congruent mod 8.
+  auto tile_bm = [&](int lin) { return ((lin >> 3) / gnp) * 8 + (lin & 7); };
+  auto next_tile = [&](int lin) {
+    while (lin < pa.ntl && tile_bm(lin) >= a.gm) lin += (int)gridDim.x;
+    return lin;
+  };
+  // per-tile state of the K loop (recomputed by setup_tile)
+  int m0 = 0, n0 = 0, y_off = 0, b0 = 0;
+  // source rows of this lane's window pieces, packed: bits [0, 14) the row of
+  // source-row parity 0, [14, 28) of parity 1 (kRowPad = zero padding), [28, 31)
+  // the sample of the tile (one register per piece instead of a byte offset per
+  // parity: the 128-register tiles have none to spare)
+  constexpr uint32_t kRowPad = 0x3fffu;
+  uint32_t arow[KPW];
+  int boff[NBW];
+  int bstage = 0;
+  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(a.x), 0, 0x7fffffff, 0x00020000);
+  __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(a.w), 0, 0x7fffffff, 0x00020000);
+
+  // Everything the K loop needs of tile `lin`.  Window pieces: piece j of the
+  // window of pass p -> buffer p & 1, bytes [j KiB, (j+1) KiB): lane L lands on
+  // (row 16 j + L/4, slot L & 3) and fetches the chunk that slot holds after
+  // the swizzle.  Wave w owns pieces j = k NW + w; the source offset of (k,
+  // source-row parity) at channel chunk 0 is computed ONCE per tile (the hot
+  // loop only passes the chunk offset as the scalar operand).
+  auto setup_tile = [&](int lin) {
+    // (lane ids re-derived from an opaque copy of the thread id: nothing of this
+    // block then stays in registers across the K loop)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jq = lin >> 3;
+    const int np_i = jq % gnp;
+    const int bm = (jq / gnp) * 8 + (lin & 7);
+    const int bn = np_i % a.gn;
+    const int phase = np_i / a.gn;
+    const uint16_t* __restrict__ wp = a.w + (long long)phase * a.w_phase_stride;
+    const int off = a.off + phase * a.off_phase_step;
+    y_off = a.y_off + phase * a.yoff_phase_step;
+    m0 = bm * TM;
+    n0 = bn * TN;
+    b0 = m0 / a.Lu;                         // first sample of the tile
+    const int u00 = m0 - b0 * a.Lu;         // its first output row (nseg == 1)
+    // per-sample phase shifts of the tile's segments
+    if (a.shifts != nullptr && tid < a.nseg) {
+      const int b = b0 + tid;
+      sh_lds[tid] = b < a.nB ? a.shifts[b / a.seg_size] : 0;
+    }
+    __syncthreads();
+    // (rows counted from the tile's first sample; padding rows become an offset
+    // past num_records at issue time: the buffer form of the DMA then fetches
+    // zeros, so there is no zero page and no 64-bit select in the loop)
+#pragma unroll
+    for (int k = 0; k < KPW; ++k) {
+      const int row = (k * NW + wave) * 16 + (lane >> 2);
+      int seg = 0;
+      if (a.nseg > 1) seg = __float2int_rz(((float)row + 0.5f) * pa.inv_WRs);
+      const int wr = row - seg * pa.WRs;
+      const int b = b0 + seg;
+      const int u0 = a.nseg > 1 ? 0 : u00;
+      const int sft = a.shifts != nullptr && seg < a.nseg ? sh_lds[seg] : 0;
+      uint32_t w = (uint32_t)seg << 28;
+#pragma unroll
+      for (int par = 0; par < R; ++par) {
+        uint32_t rr = kRowPad;
+        if (row < pa.wrows && b < a.nB) {
+          int srow = R * (u0 + wr) + off + par;
+          if (srow >= 0 && srow < a.Lx) {
+            if (a.shifts) srow = shuffle_src(srow, sft, a.Lx);
+            rr = (uint32_t)srow;
+          }
+        }
+        w |= rr << (14 * par);
+      }
+      if constexpr (ALDS) arow_lds[k * (NW * 64) + tid] = w;
+      else arow[k] = w;
+    }
+    rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(a.x + (long long)b0 * a.Lx * a.Cx), 0, 0x7fffffff,
+        0x00020000);
+    // weight stages: wave w issues pieces w*NBW + i of a stage: lane L lands at
+    // slot byte piece*1024 + L*16 = (row, chunk slot c') and fetches chunk
+    // c' ^ swz(row)
+    rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wp), 0,
+                                           0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+      const int pe = ((wave * NBW + i) * 1024 + lane * 16) / 2;  // element offset
+      int row = pe / kRowB;
+      const int cs = (pe % kRowB) / 8;
+      const int c = cs ^ ((row >> 1) & 7);
+      row += n0;
+      if (row >= pa.npad_rows) row = pa.npad_rows - 1;  // columns past N: unused
+      boff[i] = (row * a.Kpack + c * 8) * 2;
+    }
+    // (one running scalar offset: + one 64-deep stage per issue)
+    bstage = chunk0 * a.Fp * 16;
+  };
+  // issue slot k of pass p (k compile-time: the row words stay in registers)
+  auto issue_a_piece = [&](int p, int k, uint32_t w) {
+    int par, add;
+    uint32_t qb;
+    bool pad = false;
+    if (!NRW || p < full_passes) {
       const int cc = R == 2 ? (p >> 1) : p;
-      o = (R == 2 && (p & 1)) ? o1 : o0;
+      par = R == 2 ? (p & 1) : 0;
       add = (chunk0 + cc) * 64;
+      qb = (uint32_t)aq * 16;
     } else {
       // narrow last chunk: chunk q of a row = the first 8-channel group of
       // source-row parity q (q < 2; the rest of the row is never read)
-      const uint32_t sel = (q & 1) ? o1 : o0;
-      o = (q >= 2 || sel == ~0u) ? ~0u : sel - q * 16;
+      par = aq & 1;
+      pad = aq >= 2;
       add = (chunk0 + a.nchunks - 1) * 64;
+      qb = 0;
     }
-    // (opaque to LICM: hoisted out of the stage loop, the offsets of all slots
-    // would sit in registers for a whole pass)
-    asm volatile("" : "+v"(o));
+    const uint32_t rr = (w >> (14 * par)) & kRowPad;
+    // (24-bit multiply: sample * Lx + row < 2^17, row bytes < 2^12)
+    uint32_t o = __umul24((w >> 28) * (uint32_t)a.Lx + rr, (uint32_t)a.Cx * 2) + qb;
+    if (pad || rr == kRowPad) o = ~0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
         rx,
         (__attribute__((address_space(3))) void*)(ldsA + (p & 1) * ABYTES +
@@ -202,7 +271,10 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     constexpr int K = decltype(k_tag)::value;
     if constexpr (K < KPW) {
       if ((K * NW + wave) < pa.npa) {
-        issue_a_piece(p, K, aoff[K][0], aoff[K][R - 1], aq);
+        if constexpr (ALDS)
+          issue_a_piece(p, K, arow_lds[K * (NW * 64) + (int)threadIdx.x]);
+        else
+          issue_a_piece(p, K, arow[K]);
         return 1;
       }
     }
@@ -214,29 +286,14 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
 #pragma unroll
     for (int k = 0; k < KPW; ++k)
       if (k >= k0 && k < k1 && (k * NW + wave) < pa.npa) {
-        issue_a_piece(p, k, aoff[k][0], aoff[k][R - 1], aq);
+        if constexpr (ALDS)
+          issue_a_piece(p, k, arow_lds[k * (NW * 64) + (int)threadIdx.x]);
+        else
+          issue_a_piece(p, k, arow[k]);
         ++n;
       }
     return n;
   };
-  // ---- weight stages ---------------------------------------------------------
-  // wave w issues pieces w*NBW + i of a stage: lane L lands at slot byte
-  // piece*1024 + L*16 = (row, chunk slot c') and fetches chunk c' ^ swz(row)
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint16_t*>(wp), 0, 0x7fffffff, 0x00020000);
-  int boff[NBW];
-#pragma unroll
-  for (int i = 0; i < NBW; ++i) {
-    const int pe = ((wave * NBW + i) * 1024 + lane * 16) / 2;  // element offset
-    int row = pe / kRowB;
-    const int cs = (pe % kRowB) / 8;
-    const int c = cs ^ ((row >> 1) & 7);
-    row += n0;
-    if (row >= pa.npad_rows) row = pa.npad_rows - 1;  // columns past N: unused
-    boff[i] = (row * a.Kpack + c * 8) * 2;
-  }
-  // (one running scalar offset: + one 64-deep stage per issue)
-  int bstage = chunk0 * a.Fp * 16;
   auto issue_b = [&](int slot_idx) {
     uint16_t* slot = ldsB + slot_idx * kBufB;
 #pragma unroll
@@ -245,6 +302,13 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
           rw, (__attribute__((address_space(3))) void*)(slot + (wave * NBW + i) * 512),
           16, boff[i], bstage, 0, 0);
     bstage += KS * 32 * 2;
+  };
+  // window of pass 0 and weight stages 0..2 of the tile set up last
+  auto issue_prologue = [&]() {
+    issue_a_range(0, 0, KPW);
+    issue_b(0);
+    if (pa.total_stages > 1) issue_b(1);
+    if (pa.total_stages > 2) issue_b(2);
   };
 
   // ---- fragment addresses ----------------------------------------------------
@@ -275,9 +339,13 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   // may hold anything finite)
   const int half_taps = a.taps >> 1;
   auto naddr = [&](int s, int ks, int buf_off) {
-    int idx = 4 * ((s & 1) * 2 + ks) + g;
+    // (recomputed per use: hoisted, the eight addresses of the narrow pass sat in
+    // registers -- then in scratch -- across every full pass)
+    int gq = g;
+    asm volatile("" : "+v"(gq));
+    int idx = 4 * ((s & 1) * 2 + ks) + gq;
     idx = idx < half_taps ? idx : half_taps - 1;
-    return lds0 + buf_off + sw64(rowb0 - g * 16 + idx * 64 + (s >> 1) * 16);
+    return lds0 + buf_off + sw64(rowb0 - gq * 16 + idx * 64 + (s >> 1) * 16);
   };
   // B: byte offset of this lane's fragment row in ring slot 0 per K-step
   const int swzB = (rM >> 1) & 7;
@@ -303,16 +371,16 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   };
   using X0 = std::integral_constant<int, 0>;
 
+  // The weights are the MFMA's A operand and the window its B operand: the
+  // accumulator register r of lane (g, rM) is then output column 4 g + r of tile
+  // row rM -- four CONSECUTIVE channels of one row per lane, which the epilogue
+  // turns into 16-byte row-contiguous stores with lane swaps alone (no LDS).
   f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto mfma_step = [&](const act8(&af)[MT], const act8(&bf)[NT]) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) mfma_acc(acc[mt][nt], af[mt], bf[nt]);
+      for (int nt = 0; nt < NT; ++nt) mfma_acc(acc[mt][nt], bf[nt], af[mt]);
   };
   // counted wait at a stage boundary: all but this wave's newest DMAs (weight
   // stage gs + 2 if it exists, the previous stage's `na` window pieces) done
@@ -331,18 +399,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   using std::integral_constant;
   using I0 = integral_constant<int, 0>;
   using I1 = integral_constant<int, 1>;
-
-  // ---- prologue: window of pass 0, weight stages 0..2, first fragments --------
-  issue_a_range(0, 0, KPW);
-  issue_b(0);
-  if (pa.total_stages > 1) issue_b(1);
-  if (pa.total_stages > 2) issue_b(2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
   act8 af0[MT], bf0[NT], af1[MT], bf1[NT];
-  read_b(bf0, I0{}, I0{});
-  read_a(af0, full_passes > 0 ? aaddr[0] : naddr(0, 0, 0), X0{});
-  lds_wait();
 
   // One pass, NSTG stages unrolled.  aaddr[] points into the window buffer of
   // the current pass (the buffers alternate: +-ABYTES on every tap address at
@@ -356,7 +413,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     // (every other pass is followed by at least 4 stages)
     const bool last = p + 1 == pa.npass;
     constexpr int NSTG = NARROW ? 4 : NST;
-    const bool next_narrow = p + 1 >= full_passes;  // (the pass after, if any)
+    const bool next_narrow = NRW && p + 1 >= full_passes;  // (the pass after, if any)
     const int cur_off = (p & 1) * ABYTES;
     const int delta = (p & 1) ? -ABYTES : ABYTES;
     int na_prev = 0;
@@ -400,9 +457,12 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       // (the DMA issue sits behind the reads: in front of them the LDS pipe and
       // the matrix pipe both idle while the wave builds addresses)
       if (!last || s + 3 < NSTG) issue_b(s % kSwpRing);
+      mfma_step(af1, bf1);
+      lds_wait();
       // window of the next pass: stages 0 .. NSTG - 3 of this pass, so the wait
       // of stage NSTG - 1 (which leaves only the previous stage's pieces in
-      // flight) retires all of them before the first read
+      // flight) retires all of them before the first read.  (Behind the MFMA
+      // block: the row word may come from LDS, and no fragment read is pending.)
       na_prev = 0;
       if constexpr (!NARROW && s <= NSTG - 3) {
         if (!last) {
@@ -415,249 +475,283 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
           }
         }
       }
-      mfma_step(af1, bf1);
-      lds_wait();
     });
 #pragma unroll
     for (int t = 0; t < NAA; ++t) aaddr[t] += delta;
   };
   using False = integral_constant<bool, false>;
   using True = integral_constant<bool, true>;
-  for (int p = 0; p < full_passes; ++p) run_pass(False{}, p);
-  if (a.narrow) run_pass(True{}, full_passes);
-  // (the epilogue reads the accumulators with ordinary instructions: the
-  // matrix pipe drains behind the barrier + LDS round trip in front of them)
 
-  // ---- epilogue: accumulators -> LDS -> whole-line row-contiguous stores ------
-  // (the epilogues of swconv_kernel on 16x16 accumulators)
-  // (global loads first -- bias, mask words -- so that they fly across the
-  // barrier that ends the LDS reads of the K loop)
-  float* scr = reinterpret_cast<float*>(smem) + wave * (16 * kSwpScrPitch);
-  // fused LayerNorm + LeakyReLU: the row statistics span the two waves that
-  // share a row block (wave ^ 1); their partial sums meet in a small LDS table
-  // behind the transpose scratch, gamma / beta sit next to it
-  float* part = reinterpret_cast<float*>(smem) + NW * 16 * kSwpScrPitch;
-  float* lnp = part + NW * 16 * 2;  // gamma[128] | beta[128] (zero past N)
-  const int erow = lane >> 3;
-  const int cg8 = lane & 7;
-  const bool of32 = !LN && a.out_f32;  // (the LayerNorm form stores bf16)
-  const int colA = of32 ? cg8 * 4 : cg8 * 8;
-  const int colB = of32 ? colA + 32 : colA + 4;
-  const int nA = n0 + wn * 64 + colA;
-  const int nB = n0 + wn * 64 + colB;
-  float ssq = 0.f;
-  float bv[8];
+  // ---- epilogue: accumulators -> lane swaps -> 16-byte row-contiguous stores ---
+  // Lane (g, rM) holds, per 16 x 16 block nt, columns 4 g .. 4 g + 3 of tile row
+  // rM.  v_permlane16_swap exchanges the odd 16-lane rows of block 2 p with the
+  // even rows of block 2 p + 1: afterwards lane (g, rM) owns EIGHT consecutive
+  // columns of row rM -- block 2 p + (g & 1), columns 8 (g >> 1) .. + 7 -- i.e.
+  // one 16-byte store per lane and block pair, 64 contiguous bytes per row and
+  // instruction.  No LDS round trip, no barrier.
+  auto pair8 = [&](int mt, int p, float (&v)[8]) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    bv[e] = (a.bias && nA + e < a.N) ? a.bias[nA + e] : 0.f;
-    bv[4 + e] = (a.bias && nB + e < a.N) ? a.bias[nB + e] : 0.f;
-  }
-  // Row addressing of the plain (non-LayerNorm) forms.  A wave's 16 MT rows lie
-  // in one sample (S >= 16 MT): sample index and output-side phase shift are
-  // wave-uniform, computed once (they were a division and a dependent global
-  // load per 8-row pass).  The LeakyReLU' mask words of all 2 MT passes are
-  // fetched HERE, in front of the transposes: behind each pass's wavefront
-  // fence they were MT exposed global round trips per workgroup, 26 of the 89 us
-  // of a critic input-gradient launch.
-  const int mw0 = m0 + wm * MT * 16;  // first row of this wave
-  const int bw = __builtin_amdgcn_readfirstlane(mw0 / a.Lu);
-  const int uw0 = mw0 - bw * a.Lu;
-  int oshift = 0;
-  if (!LN && a.out_shifts && bw < a.nB) oshift = a.out_shifts[bw / a.out_seg];
-  // output row of tile row r of this wave: element offset of its first column;
-  // to_side: a reflected row of the output-side PhaseShuffle adjoint
-  auto row_target = [&](int r, bool& to_side) {
-    const int u = uw0 + r;
-    int t = a.y_stride * u + y_off;
-    to_side = false;
-    if (a.out_shifts) {
-      if (oshift > 0) {
-        to_side = t >= a.Ly - oshift;
-        t = to_side ? t - (a.Ly - oshift) : t + oshift;
-      } else {
-        to_side = t < -oshift;
-        t = to_side ? t : t + oshift;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(
+          __float_as_uint(acc[mt][2 * p][r]), __float_as_uint(acc[mt][2 * p + 1][r]),
+          false, false);
+      v[r] = __uint_as_float(sw[0]);
+      v[4 + r] = __uint_as_float(sw[1]);
     }
-    return ((long long)bw * (to_side ? a.side_rows : a.Ly) + t) * a.Cy;
   };
-  uint2 mka[MT][2], mkb[MT][2];
-  if constexpr (!LN) {
-    if (a.epilogue == CG_EPI_MASK) {
+  auto epilogue = [&](int em0, int en0, int ey_off, int eb0) {
+    // the matrix pipe retires the last MFMAs (inline assembly: the compiler's
+    // hazard recognizer does not see them) before ordinary instructions read acc
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          const int r = mt * 16 + pass * 8 + erow;
-          bool to_side;
-          const long long rowoff = row_target(r, to_side);
-          mka[mt][pass] = make_uint2(0u, 0u);
-          mkb[mt][pass] = make_uint2(0u, 0u);
-          if (mw0 + r < a.M && nA < a.Cy && !to_side) {
-            mka[mt][pass] = *reinterpret_cast<const uint2*>(a.mask + rowoff + nA);
-            if (nB < a.Cy)
-              mkb[mt][pass] = *reinterpret_cast<const uint2*>(a.mask + rowoff + nB);
-          }
-        }
-    }
-  }
-  __syncthreads();
-  if constexpr (LN) {
-    if (tid < 128) {
-      lnp[tid] = tid < a.N ? a.ln_gamma[tid] : 0.f;
-      lnp[128 + tid] = tid < a.N ? a.ln_beta[tid] : 0.f;
-    }
-  }
+      for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(acc[mt][nt]));
+    // (lane ids re-derived from an opaque copy of the thread id, as in
+    // setup_tile: the epilogue keeps no register alive across the K loop)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int rM = lane & 15;
+    const int g = lane >> 4;
+    const int cq = (g & 1) * 16 + (g >> 1) * 8;  // lane's column inside a block pair
+    const int nl0 = en0 + wn * 64 + cq;  // lane's first column of block pair 0
+    float bv[2][8];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+      for (int e = 0; e < 8; ++e) {
+        const int n = nl0 + p * 32 + e;
+        bv[p][e] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+      }
+    const int mw0 = em0 + wm * MT * 16;  // first row of this wave
+    if constexpr (LN) {
+      // fused LayerNorm + LeakyReLU: a row's statistics span the two waves that
+      // share its row block (wave ^ 1); the partial sums meet in a small LDS
+      // table (double-buffered by subtile: one workgroup barrier per subtile)
+      const float invn = 1.f / (float)a.N;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        scr[(4 * g + r) * kSwpScrPitch + nt * 16 + rM] = acc[mt][nt][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int row = pass * 8 + erow;
-      const int m = m0 + (wm * MT + mt) * 16 + row;
-      if constexpr (LN) {
-        // (every lane takes part: the workgroup barrier below is uniform)
-        const f32x4 v0 =
-            *reinterpret_cast<const f32x4*>(scr + row * kSwpScrPitch + colA);
-        const f32x4 v1 =
-            *reinterpret_cast<const f32x4*>(scr + row * kSwpScrPitch + colB);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      for (int mt = 0; mt < MT; ++mt) {
+        float v[2][8];
+        pair8(mt, 0, v[0]);
+        pair8(mt, 1, v[1]);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int n = (e < 4 ? nA : nB - 4) + e;
-          // statistics of the STORED pre-activation, as the separate
-          // cg_ln_lrelu_fwd pass sees it
-          v[e] = n < a.N ? act2f(f2act(v[e] + bv[e])) : 0.f;
-          s1 += v[e];
-          s2 += v[e] * v[e];
-        }
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-          s1 += __shfl_xor(s1, o, 64);
-          s2 += __shfl_xor(s2, o, 64);
-        }
-        if (cg8 == 0)
-          *reinterpret_cast<float2*>(part + (wave * 16 + row) * 2) =
-              make_float2(s1, s2);
+          for (int e = 0; e < 8; ++e) {
+            const int n = nl0 + p * 32 + e;
+            // statistics of the STORED pre-activation, as the separate
+            // cg_ln_lrelu_fwd pass sees it
+            v[p][e] = n < a.N ? act2f(f2act(v[p][e] + bv[p][e])) : 0.f;
+            s1 += v[p][e];
+            s2 += v[p][e] * v[p][e];
+          }
+        s1 += __shfl_xor(s1, 16, 64);
+        s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        float* pt = part + (mt & 1) * (NW * 32);
+        if (g == 0)
+          *reinterpret_cast<float2*>(pt + (wave * 16 + rM) * 2) = make_float2(s1, s2);
         __syncthreads();
         const float2 o2 =
-            *reinterpret_cast<const float2*>(part + ((wave ^ 1) * 16 + row) * 2);
-        const float invn = 1.f / (float)a.N;
+            *reinterpret_cast<const float2*>(pt + ((wave ^ 1) * 16 + rM) * 2);
         const float mean = (s1 + o2.x) * invn;
         const float var = fmaxf((s2 + o2.y) * invn - mean * mean, 0.f);
         const float rstd = rsqrtf(var + a.ln_eps);
-        if (m < a.M && nA < a.Cy) {
+        const int m = mw0 + mt * 16 + rM;
+        if (m < a.M) {
           const int b = m / a.Lu;
           const int u = m - b * a.Lu;
           const long long ridx =
-              (long long)b * a.Ly + (long long)a.y_stride * u + y_off;
+              (long long)b * a.Ly + (long long)a.y_stride * u + ey_off;
           const long long rowoff = ridx * a.Cy;
-          const int lc = wn * 64 + colA;
-          const f32x4 g0 = *reinterpret_cast<const f32x4*>(lnp + lc);
-          const f32x4 g1 = *reinterpret_cast<const f32x4*>(lnp + lc + 4);
-          const f32x4 b0v = *reinterpret_cast<const f32x4*>(lnp + 128 + lc);
-          const f32x4 b1v = *reinterpret_cast<const f32x4*>(lnp + 128 + lc + 4);
-          float hv[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float t = (v[e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) +
-                            (e < 4 ? b0v[e] : b1v[e - 4]);
-            hv[e] = fmaxf(t, a.alpha * t);
+          for (int p = 0; p < 2; ++p) {
+            const int n = nl0 + p * 32;
+            if (n < a.Cy) {
+              const int lc = n - en0;  // (en0 == 0: one column tile)
+              const f32x4 g0 = *reinterpret_cast<const f32x4*>(lnp + lc);
+              const f32x4 g1 = *reinterpret_cast<const f32x4*>(lnp + lc + 4);
+              const f32x4 b0v = *reinterpret_cast<const f32x4*>(lnp + 128 + lc);
+              const f32x4 b1v = *reinterpret_cast<const f32x4*>(lnp + 128 + lc + 4);
+              float hv[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float t =
+                    (v[p][e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) +
+                    (e < 4 ? b0v[e] : b1v[e - 4]);
+                hv[e] = fmaxf(t, a.alpha * t);
+              }
+              // (forward-only callers pass no statistics buffers: the
+              // pre-activation is then not stored either)
+              if (a.ln_mean)
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.y) +
+                                          rowoff + n) =
+                    make_uint4(pack2act(v[p][0], v[p][1]), pack2act(v[p][2], v[p][3]),
+                               pack2act(v[p][4], v[p][5]), pack2act(v[p][6], v[p][7]));
+              *reinterpret_cast<uint4*>(a.ln_h + rowoff + n) =
+                  make_uint4(pack2act(hv[0], hv[1]), pack2act(hv[2], hv[3]),
+                             pack2act(hv[4], hv[5]), pack2act(hv[6], hv[7]));
+            }
           }
-          // (forward-only callers pass no statistics buffers: the
-          // pre-activation is then not stored either)
-          if (a.ln_mean)
-            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.y) + rowoff +
-                                      nA) =
-                make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]),
-                           pack2act(v[4], v[5]), pack2act(v[6], v[7]));
-          *reinterpret_cast<uint4*>(a.ln_h + rowoff + nA) =
-              make_uint4(pack2act(hv[0], hv[1]), pack2act(hv[2], hv[3]),
-                         pack2act(hv[4], hv[5]), pack2act(hv[6], hv[7]));
-          if (a.ln_mean && wn == 0 && cg8 == 0) {
+          if (a.ln_mean && wn == 0 && g == 0) {
             a.ln_mean[ridx] = mean;
             a.ln_rstd[ridx] = rstd;
           }
         }
       }
-      if (!LN && m < a.M && nA < a.Cy) {
+    } else {
+      // Row addressing.  A wave's 16 MT rows lie in one sample (S >= 16 MT):
+      // sample index and output-side phase shift are wave-uniform.
+      const int bw = __builtin_amdgcn_readfirstlane(mw0 / a.Lu);
+      const int uw0 = mw0 - bw * a.Lu;
+      int oshift = 0;
+      if (a.out_shifts && bw < a.nB) oshift = a.out_shifts[bw / a.out_seg];
+      // output row of tile row r of this wave: element offset of its first
+      // column; to_side: a reflected row of the output-side PhaseShuffle adjoint
+      auto row_target = [&](int r, bool& to_side) {
+        const int u = uw0 + r;
+        int t = a.y_stride * u + ey_off;
+        to_side = false;
+        if (a.out_shifts) {
+          if (oshift > 0) {
+            to_side = t >= a.Ly - oshift;
+            t = to_side ? t - (a.Ly - oshift) : t + oshift;
+          } else {
+            to_side = t < -oshift;
+            t = to_side ? t : t + oshift;
+          }
+        }
+        return ((long long)bw * (to_side ? a.side_rows : a.Ly) + t) * a.Cy;
+      };
+      // the LeakyReLU' mask words of every subtile are fetched up front (one
+      // exposed round trip instead of one per subtile)
+      uint4 mk[MT][2];
+      if (a.epilogue == CG_EPI_MASK) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int r = mt * 16 + rM;
+          bool to_side;
+          const long long rowoff = row_target(r, to_side);
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            mk[mt][p] = make_uint4(0u, 0u, 0u, 0u);
+            if (mw0 + r < a.M && nl0 + p * 32 < a.Cy && !to_side)
+              mk[mt][p] = *reinterpret_cast<const uint4*>(a.mask + rowoff + nl0 +
+                                                          p * 32);
+          }
+        }
+      }
+      float ssq = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int r = mt * 16 + rM;
         bool to_side;
-        const long long rowoff = row_target(mt * 16 + row, to_side);
-        const f32x4 v0 =
-            *reinterpret_cast<const f32x4*>(scr + row * kSwpScrPitch + colA);
-        const f32x4 v1 =
-            *reinterpret_cast<const f32x4*>(scr + row * kSwpScrPitch + colB);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const bool okB = nB < a.Cy;
+        const long long rowoff = row_target(r, to_side);
+        const bool row_ok = mw0 + r < a.M;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bv[e];
-        if (a.epilogue == CG_EPI_LRELU) {
+        for (int p = 0; p < 2; ++p) {
+          float v[8];
+          pair8(mt, p, v);  // (every lane takes part in the swap)
+          const int n = nl0 + p * 32;
+          if (row_ok && n < a.Cy) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], a.alpha * v[e]);
-        } else if (a.epilogue == CG_EPI_MASK && !to_side) {
-          if (a.out_shifts) {
+            for (int e = 0; e < 8; ++e) v[e] += bv[p][e];
+            if (a.epilogue == CG_EPI_LRELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = act2f(f2act(v[e]));
+              for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], a.alpha * v[e]);
+            } else if (a.epilogue == CG_EPI_MASK && !to_side) {
+              if (a.out_shifts) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = act2f(f2act(v[e]));
+              }
+              const uint4 h4 = mk[mt][p];
+              const uint32_t hw[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const uint16_t hv = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
+                v[e] *= (act2f(hv) > 0.f) ? 1.f : a.alpha;
+              }
+            } else if (a.epilogue == CG_EPI_SIGMOID) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (n + e >= a.N) v[e] = 0.f;
+            if (a.rowsumsq) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
+            }
+            if (a.out_f32) {
+              float* dst = reinterpret_cast<float*>(a.y) + zsplit * a.split_stride +
+                           rowoff + n;
+              *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+              *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+              uint16_t* dst =
+                  (to_side ? a.side : reinterpret_cast<uint16_t*>(a.y)) + rowoff + n;
+              *reinterpret_cast<uint4*>(dst) =
+                  make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]),
+                             pack2act(v[4], v[5]), pack2act(v[6], v[7]));
+            }
           }
-          const uint2 ha = mka[mt][pass];
-          const uint2 hb = mkb[mt][pass];
-          const uint32_t hw[4] = {ha.x, ha.y, hb.x, hb.y};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const uint16_t hv = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
-            v[e] *= (act2f(hv) > 0.f) ? 1.f : a.alpha;
-          }
-        } else if (a.epilogue == CG_EPI_SIGMOID) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (nA + e >= a.N) v[e] = 0.f;
-          if (nB + e >= a.N) v[4 + e] = 0.f;
-        }
-        if (a.rowsumsq) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
-        }
-        if (a.out_f32) {
-          float* dst = reinterpret_cast<float*>(a.y) + zsplit * a.split_stride + rowoff;
-          *reinterpret_cast<f32x4*>(dst + nA) = f32x4{v[0], v[1], v[2], v[3]};
-          if (okB)
-            *reinterpret_cast<f32x4*>(dst + nB) = f32x4{v[4], v[5], v[6], v[7]};
-        } else {
-          uint16_t* dst =
-              (to_side ? a.side : reinterpret_cast<uint16_t*>(a.y)) + rowoff + nA;
-          *reinterpret_cast<uint4*>(dst) =
-              make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]),
-                         pack2act(v[4], v[5]), pack2act(v[6], v[7]));
+      }
+      if (a.rowsumsq) {
+        // the whole tile belongs to one sample (nseg == 1, checked on the host):
+        // one f32 atomic per workgroup
+        ssq = wave_sum(ssq);
+        if (lane == 0) wsum[wave] = ssq;
+        __syncthreads();
+        if (tid == 0 && em0 < a.M) {
+          float t = 0.f;
+          for (int w = 0; w < NW; ++w) t += wsum[w];
+          atomicAdd(a.rowsumsq + eb0, t);
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  if (a.rowsumsq) {
-    // the whole tile belongs to one sample (nseg == 1, checked on the host): one
-    // f32 atomic per workgroup
-    ssq = wave_sum(ssq);
-    float* wsum = reinterpret_cast<float*>(smem) + NW * 16 * kSwpScrPitch;
-    if (lane == 0) wsum[wave] = ssq;
-    __syncthreads();
-    if (tid == 0 && m0 < a.M) {
-      float t = 0.f;
-      for (int w = 0; w < NW; ++w) t += wsum[w];
-      atomicAdd(a.rowsumsq + b0, t);
+  };
+
+  // ---- the tile loop -----------------------------------------------------------
+  int lin = next_tile((int)blockIdx.x);
+  if (lin >= pa.ntl) return;
+  setup_tile(lin);
+  issue_prologue();
+  while (true) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // window of pass 0 and weight stages 0..2 have landed (and the stores of the
+    // previous tile's epilogue have been taken)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_b(bf0, I0{}, I0{});
+    read_a(af0, (!NRW || full_passes > 0) ? aaddr[0] : naddr(0, 0, 0), X0{});
+    lds_wait();
+    for (int p = 0; p < full_passes; ++p) run_pass(False{}, p);
+    if constexpr (NRW) run_pass(True{}, full_passes);
+    // (the tap addresses toggle window buffers per pass: back to buffer 0)
+    if (pa.npass & 1) {
+#pragma unroll
+      for (int t = 0; t < NAA; ++t) aaddr[t] -= ABYTES;
     }
+    // epilogue of this tile, then -- its stores still in flight -- the DMAs of
+    // the next tile's prologue: the two bursts share the memory system instead
+    // of queueing behind a workgroup launch
+    const int em0 = m0, en0 = n0, ey_off = y_off, eb0 = b0;
+    epilogue(em0, en0, ey_off, eb0);
+    lin = next_tile(lin + (int)gridDim.x);
+    if (lin >= pa.ntl) break;
+    // (every wave is past the last LDS read of the K loop: setup_tile's barrier)
+    setup_tile(lin);
+    issue_prologue();
   }
 }
 
@@ -665,25 +759,66 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
 // directly in a __global__ template the host pass emits no stub for it)
 // (second launch bound = waves per SIMD the register budget must allow: the
 // 32-row wave tiles run 3 four-wave or 2 eight-wave workgroups per CU)
-template <int R, int WM, int WN, int MT, bool LN = false>
+template <int R, int WM, int WN, int MT, bool LN = false, bool NRW = false>
 __global__ __launch_bounds__(WM* WN * 64, MT == 2 ? (WM * WN == 8 ? 4 : 3) : 2) void
 swconv_swp_kernel(SwpArgs pa) {
-  swconv_swp_body<R, WM, WN, MT, LN>(pa);
+  swconv_swp_body<R, WM, WN, MT, LN, NRW>(pa);
 }
 
-template <int R, int WM, int WN, int MT, bool LN = false>
-int launch_swp(const SwpArgs& pa, dim3 grid, size_t lds, bool dry, hipStream_t s) {
+// Workgroups of one instantiation a CU holds at `lds` bytes of dynamic LDS
+// (registers, LDS and the wave slots together; asked of the runtime once).
+template <int R, int WM, int WN, int MT, bool LN, bool NRW>
+int swp_occupancy(size_t lds) {
+  static size_t known_lds = 0;
+  static int known = 0;
+  if (known == 0 || known_lds != lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &nb,
+            reinterpret_cast<const void*>(&swconv_swp_kernel<R, WM, WN, MT, LN, NRW>),
+            WM * WN * 64, lds) != hipSuccess || nb < 1)
+      nb = 1;
+    known = nb;
+    known_lds = lds;
+  }
+  return known;
+}
+
+inline int swp_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        prop.multiProcessorCount < 1)
+      return 256;
+    cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+
+template <int R, int WM, int WN, int MT, bool LN = false, bool NRW = false>
+int launch_swp(const SwpArgs& pa, unsigned gy, size_t lds, bool dry, hipStream_t s) {
   if (dry) return 0;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&swconv_swp_kernel<R, WM, WN, MT, LN>),
+        reinterpret_cast<const void*>(&swconv_swp_kernel<R, WM, WN, MT, LN, NRW>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  CG_LAUNCH_PROF(CG_FAMILY_SWCONV, (swconv_swp_kernel<R, WM, WN, MT, LN>), grid,
-                 dim3(WM * WN * 64), lds, s, pa);
+  // persistent workgroups: one resident set walks all tiles (a multiple of 8
+  // workgroups, so each keeps its XCD residue over its tiles)
+  long long slots =
+      (long long)swp_num_cus() * swp_occupancy<R, WM, WN, MT, LN, NRW>(lds);
+  slots = slots / 8 * 8;
+  if (gy > 1) slots = (slots / gy) / 8 * 8;  // the split-K slices share the CUs
+  if (slots < 8) slots = 8;
+  const unsigned gx = (unsigned)(pa.ntl < slots ? pa.ntl : slots);
+  CG_LAUNCH_PROF(CG_FAMILY_SWCONV, (swconv_swp_kernel<R, WM, WN, MT, LN, NRW>),
+                 dim3(gx, gy), dim3(WM * WN * 64), lds, s, pa);
   CG_LAUNCH_CHECK();
 }
 
@@ -694,6 +829,7 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   // uniform 32-channel K walk, one tap per K-step; the fused LayerNorm needs
   // whole rows in the workgroup
   if (a.CK != 32 || a.taps % stride) return CG_EINVAL;
+  if (a.Lx >= 0x3fff) return CG_EINVAL;  // window rows travel as 14-bit fields
   // split-K (blockIdx.y walks its share of the channel chunks, f32 partial sums
   // into the caller's workspace): whole chunks only
   if (ksplit > 1 && (a.narrow || a.epilogue == CG_EPI_LN_LRELU)) return CG_EINVAL;
@@ -727,23 +863,27 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   const int tm = wm * mt * 16;
   const int npa_max = tm / 16 + 6;
   if (pa.npa > npa_max) return CG_EINVAL;
-  size_t lds = (size_t)2 * npa_max * 1024 + (size_t)kSwpRing * tn * 64 * 2 + 128;
-  // transpose scratch + rowsumsq slots / LayerNorm tables behind it
-  const size_t epi = (size_t)nw * 16 * kSwpScrPitch * 4 + nw * 16 * 2 * 4 + 256 * 4 + 64;
-  if (lds < epi) lds = epi;
+  // windows + weight ring + [phase shifts | rowsumsq slots]; the fused
+  // LayerNorm adds its statistics table (2 x nw x 16 x 2 floats) and gamma / beta
+  size_t lds = (size_t)2 * npa_max * 1024 + (size_t)kSwpRing * tn * 64 * 2 + 128 + 64;
+  if (ln) lds += (size_t)2 * nw * 32 * 4 + 256 * 4;
+  // (row words of the window pieces of the stride-2 8-wave 256 x 64 tile)
+  if (stride == 2 && nw == 8 && wn == 1 && mt == 2)
+    lds += (size_t)((tm / 16 + 6 + nw - 1) / nw) * nw * 64 * 4;
   if (lds > 160 * 1024) return CG_EINVAL;
-  dim3 grid((unsigned)(((a.gm + 7) / 8) * 8 * a.gn * a.gp),
-            (unsigned)(ksplit > 1 ? ksplit : 1));
+  pa.ntl = ((a.gm + 7) / 8) * 8 * a.gn * a.gp;
+  const unsigned grid = (unsigned)(ksplit > 1 ? ksplit : 1);
   if (ln) {
     if (wm == 4 && mt == 4) return launch_swp<1, 4, 2, 4, true>(pa, grid, lds, dry, stream);
     if (wm == 2 && mt == 4) return launch_swp<1, 2, 2, 4, true>(pa, grid, lds, dry, stream);
     if (wm == 4 && mt == 2) return launch_swp<1, 4, 2, 2, true>(pa, grid, lds, dry, stream);
     return CG_EINVAL;
   }
-#define CG_SWP(RR, WM, WN, MM)                                  \
-  if (stride == RR && wm == WM && wn == WN && mt == MM)         \
-    return launch_swp<RR, WM, WN, MM>(pa, grid, lds, dry, stream);
-#define CG_SWP_R(WM, WN, MM) CG_SWP(1, WM, WN, MM) CG_SWP(2, WM, WN, MM)
+#define CG_SWP(RR, WM, WN, MM, NN)                                          \
+  if (stride == RR && wm == WM && wn == WN && mt == MM && narrow == NN)     \
+    return launch_swp<RR, WM, WN, MM, false, NN != 0>(pa, grid, lds, dry, stream);
+#define CG_SWP_R(WM, WN, MM) \
+  CG_SWP(1, WM, WN, MM, 0) CG_SWP(2, WM, WN, MM, 0) CG_SWP(2, WM, WN, MM, 1)
   CG_SWP_R(8, 1, 4)   // 512 x 64, 8 waves
   CG_SWP_R(4, 1, 4)   // 256 x 64, 4 waves
   CG_SWP_R(4, 2, 4)   // 256 x 128, 8 waves

@@ -516,7 +516,8 @@ class WGAN_GP(GAN):
     # graphed call.  Measured: replaying the OLD graphs after eager steps gave
     # garbage penalties in 6 of 14 processes (tools/dbg notes in DESIGN.md);
     # freshly captured ones in 0 of 14
-    st.pop('graph', None)
+    if not getattr(self, '_keep_graphs_across_eager', False):
+      st.pop('graph', None)
     return self._train_body(real, rand)
 
   def validate(self, inputs, rand=None):
