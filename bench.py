@@ -303,9 +303,11 @@ def main():
           hp, B, batched_g=world == 1 and _w._BATCH_G and not _w._FORCE_SPLIT)
       roofline['algorithmic_hbm_bytes_per_launch'] = ab / alaunch
       import glob
-      pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles',
-                                           'r??_pmc_traffic.json')))
-      if pmcs and default_workload:
+      # (measured per workload: the default one and BASELINE configs[4])
+      pmcs = sorted(glob.glob(os.path.join(
+          ROOT, 'profiles', 'r??_cfg5_pmc_traffic.json'
+          if cfg_name == 'cfg5' else 'r??_pmc_traffic.json')))
+      if pmcs and (default_workload or cfg_name == 'cfg5'):
         # HBM bytes per launch from rocprofv3 PMC passes of this same command
         # (tools/pmc_traffic.sh: FETCH_SIZE x2 per the gfx950 correction +
         # WRITE_SIZE, separate passes).  A committed measurement, not a live

@@ -696,11 +696,17 @@ __global__ __launch_bounds__(kThreads) void adam_ls_kernel(
     float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
     float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
     float gscale, const float* __restrict__ ls) {
+  // (the step size once per block, not two powf and a sqrtf per element)
+  __shared__ float s_lr_t;
+  if (threadIdx.x == 0) {
+    const float t = ls[2] + 1.f;
+    s_lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  }
+  __syncthreads();
   const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
   if (ls[3] == 0.f) return;  // non-finite gradients: the update is skipped
-  const float t = ls[2] + 1.f;
-  const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  const float lr_t = s_lr_t;
   const float g = grad[i] * (gscale / ls[0]);
   const float mi = b1 * m[i] + (1.f - b1) * g;
   const float vi = b2 * v[i] + (1.f - b2) * g * g;

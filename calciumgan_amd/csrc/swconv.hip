@@ -972,7 +972,7 @@ extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {
 struct SplitProf { bool on; hipEvent_t start; };
 static SplitProf g_split_prof = {false, nullptr};
 // cg_swconv_check: walk the whole validation + dispatch path without launching
-static bool g_dry_run = false;
+static thread_local bool g_dry_run = false;  // (per calling thread: the C ABI may be driven from several)
 
 template <int R, int MF, int WGN, int MT, int KS, bool UNI, bool SP = false,
           bool LN = false>

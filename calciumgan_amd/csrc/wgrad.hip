@@ -261,6 +261,23 @@ struct RingFrags {  // two sets: the running K-step's and the next one's
   s16x4 bl[2][4], bh[2][4];  // g: 16-column group
 };
 
+// s_waitcnt lgkmcnt(0) that NAMES the fragment set its reads filled: the reads
+// are inline assembly, so the compiler takes their outputs as defined when
+// issued; whatever it builds from them (the register pairs join() forms, a copy)
+// must not move in front of the wait.  The in/out operands make every later use
+// of the set depend on this statement.
+__device__ __forceinline__ void lds_wait_set(RingFrags& f, int set) {
+#define CG_T2(a, i) "+v"(f.a[set][i])
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : CG_T2(al, 0), CG_T2(al, 1), CG_T2(al, 2), CG_T2(al, 3), CG_T2(al, 4),
+                 CG_T2(al, 5), CG_T2(ah, 0), CG_T2(ah, 1), CG_T2(ah, 2), CG_T2(ah, 3),
+                 CG_T2(ah, 4), CG_T2(ah, 5), CG_T2(bl, 0), CG_T2(bl, 1), CG_T2(bl, 2),
+                 CG_T2(bl, 3), CG_T2(bh, 0), CG_T2(bh, 1), CG_T2(bh, 2), CG_T2(bh, 3)
+               :
+               : "memory");
+#undef CG_T2
+}
+
 template <int TT>
 __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
                                                 unsigned char* smem, int bx,
@@ -469,7 +486,7 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
       }
       if constexpr (j == 11) mid();
     });
-    lds_wait();
+    lds_wait_set(f, SET ^ 1);
   };
   // bias gradient: column sums of the g tile in slot `soff` (asm reads, as the
   // fragments: consumed after the phase's wait)
@@ -487,6 +504,10 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
     }
   };
   auto colsum_add = [&](int tile) {
+    // (called behind the wait of the step that followed colsum_read: these
+    // statements keep the sums below from moving in front of that wait)
+#pragma unroll
+    for (int k = 0; k < RPG; ++k) asm volatile("" : "+v"(csw[k]));
 #pragma unroll
     for (int k = 0; k < RPG; ++k)
       if ((long long)tile * TT + cs_row + k < a.bias_rows) {
@@ -504,7 +525,7 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
   static_for<20>([&](auto r_tag) {
     read_one(integral_constant<int, 0>{}, integral_constant<int, 0>{}, r_tag);
   });
-  lds_wait();
+  lds_wait_set(f, 0);
 
   {
     int soff = 0;  // ring slot (byte offset) of tile i

@@ -512,12 +512,11 @@ class WGAN_GP(GAN):
       if st['calls'] > _GRAPH_WARMUP_CALLS:
         return self._train_graphed(real, st)
     # an eager step between replays (injected randomness, main.py's --profile
-    # window): the captured graphs are dropped and re-captured at the next
-    # graphed call.  Measured: replaying the OLD graphs after eager steps gave
-    # garbage penalties in 6 of 14 processes (tools/dbg notes in DESIGN.md);
-    # freshly captured ones in 0 of 14
-    if not getattr(self, '_keep_graphs_across_eager', False):
-      st.pop('graph', None)
+    # window).  The captured graphs stay valid: they hold pointers to buffers
+    # that live as long as this object, and nothing in them depends on what ran
+    # in between.  (Round 2 dropped them here after "stale graph" penalties of
+    # 1e25; the cause was a hipMemsetAsync NODE inside the captured step --
+    # cg_rownorm's -- not stale memory: DESIGN.md section 8.)
     return self._train_body(real, rand)
 
   def validate(self, inputs, rand=None):

@@ -17,6 +17,40 @@ import numpy as np
 from . import h5_helper
 
 
+class LazyRows(object):
+  """Rows `index` of a host array, gathered when first looked at.  The train
+  loop never reads the spike half of a batch (reference main.py:39 `for signal,
+  _ in train_ds`); gathered eagerly, 128 x 2048 x 102 spikes per step were
+  ~10 ms of host time in front of every train() -- as long as the step itself
+  (main.py at cfg2: 24 -> 13 ms per step)."""
+
+  def __init__(self, array, index):
+    self._array, self._index, self._rows = array, index, None
+
+  def _get(self):
+    if self._rows is None:
+      self._rows = self._array[self._index]
+    return self._rows
+
+  def __array__(self, dtype=None, copy=None):
+    r = self._get()
+    return r if dtype is None else r.astype(dtype)
+
+  def __getitem__(self, k):
+    return self._get()[k]
+
+  def __len__(self):
+    return len(self._index)
+
+  @property
+  def shape(self):
+    return (len(self._index),) + tuple(self._array.shape[1:])
+
+  @property
+  def dtype(self):
+    return self._array.dtype
+
+
 class ArrayDataset(object):
   """Iterable of (signal, spike) batches; reshuffled every epoch when asked
   (tf.data shuffle(buffer) + batch, dataset_helper.py:170-174)."""
@@ -49,9 +83,9 @@ class ArrayDataset(object):
       if self._dev_signals is not None:
         import torch
         jj = torch.from_numpy(j).to(self._dev_signals.device)
-        yield self._dev_signals.index_select(0, jj), self.spikes[j]
+        yield self._dev_signals.index_select(0, jj), LazyRows(self.spikes, j)
       else:
-        yield self.signals[j], self.spikes[j]
+        yield self.signals[j], LazyRows(self.spikes, j)
 
 
 def get_dataset_info(hparams):

@@ -48,6 +48,10 @@ def train(hparams, train_ds, gan, summary, epoch):
     if gradient_penalty is not None:
       gradient_penalties.append(gradient_penalty)
     hparams.global_step += 1
+  if summary is not None and getattr(summary, '_profile', None) is not None:
+    # an epoch of 3 .. 6 batches never reaches batch 6: close the window here
+    # (graph replay comes back, the launch profiler is switched off)
+    summary.profiler_export()
   gen_loss = float(np.mean([float(v) for v in gen_losses]))
   dis_loss = float(np.mean([float(v) for v in dis_losses]))
   gp = float(np.mean([float(v) for v in gradient_penalties

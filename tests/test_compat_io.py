@@ -148,6 +148,13 @@ def test_dataset_directory_roundtrip(tmp_path):
   assert len(batches) == 4 and batches[-1][0].shape == (2, 64, 8)  # short tail
   assert batches[0][0].dtype == np.float32
   assert sum(len(b[0]) for b in val_ds) == 6
+  # the spike half of a batch is gathered lazily (the train loop never reads
+  # it) and equals the rows of the signal half
+  order = np.concatenate([np.asarray(b[1]) for b in batches])
+  sig_order = np.concatenate([b[0] for b in batches])
+  assert batches[0][1].shape == (4,) + tuple(train_ds.spikes.shape[1:])
+  rows = [int(np.argmax((train_ds.signals == s).all(axis=(1, 2)))) for s in sig_order]
+  np.testing.assert_array_equal(order, train_ds.spikes[rows])
   # validation cache for the spike-metric scripts (dataset_helper.py:12-30)
   assert h5_helper.get(hp.validation_cache, 'spikes').dtype == np.int8
 

@@ -34,10 +34,17 @@ CONFIGS = {
 }
 
 
+# BASELINE configs[1]'s layer shapes (L 2048, 102 neurons, num_units 64, m 10) at
+# batch 2: only for the per-term gradient test (the oracle's double backward at
+# these shapes takes seconds; the whole-step tests at this size are
+# tests/test_hip_cfg2.py)
+EXTRA_CONFIGS = {'cfg2_b2': (2048, 102, 64, 24, 10, 2, True)}
+
+
 def _build(name):
   from calciumgan_amd.gan.algorithms import get_algorithm
   from calciumgan_amd.gan.models import get_models
-  L, C, U, k, m, B, ln = CONFIGS[name]
+  L, C, U, k, m, B, ln = CONFIGS[name] if name in CONFIGS else EXTRA_CONFIGS[name]
   hp = O.make_hparams(L, C, U, kernel_size=k, m=m, layer_norm=ln)
   hp.verbose = 0
   gen, dis = get_models(hp, None)
@@ -161,7 +168,8 @@ def _term_grads(hp, gen, dis, real, r, term, q):
   return torch.autograd.grad(loss, dw, allow_unused=True)
 
 
-@pytest.mark.parametrize('name', ['tiny', 'mid', 'odd_c', 'long', 'c40'])
+@pytest.mark.parametrize('name', ['tiny', 'mid', 'odd_c', 'long', 'c40',
+                                  'cfg2_b2'])
 @pytest.mark.parametrize('term', ['real', 'fake', 'gp'])
 def test_critic_loss_terms_separately(name, term):
   """Gradient of ONE term of the critic loss (wgan_gp.py:58-61) at a time (the
@@ -443,3 +451,62 @@ def test_outputs_stay_valid_across_graph_replays(use_graph):
   for i in (1, 2):
     d = np.linalg.norm(runs[True][i] - runs[False][i])
     assert d / np.linalg.norm(runs[False][i]) < 1e-3
+
+
+def test_old_graphs_replay_correctly_after_validate_and_eager_steps():
+  """Regression for round 2's "stale graph" penalties:
+  graph replays -> validate() at another batch size (new descriptors, tuning
+  launches) -> eager train() steps -> replay of the OLD graphs gave penalties of
+  1e5 .. 1e30 in most processes.  Cause: cg_rownorm zeroed its accumulator with
+  hipMemsetAsync, which inside the captured step is a memset NODE; replayed
+  after other work had run, that node no longer left zeros behind
+  (tools/stale_graph_hunt.py memsetprobe).  The library now zeroes with a
+  kernel and train() keeps its graphs across eager steps.  Checked here: the
+  old graphs are the ones replayed, every critic update's penalty is sane, and
+  the first update's penalty / loss equal the oracle's on the same draws
+  (re-drawn from the generator states saved in front of the replay)."""
+  from calciumgan_amd.gan.algorithms import get_algorithm
+  from calciumgan_amd.gan.models import get_models
+  hp = O.make_hparams(256, 16, 8, m=2)   # L/2 < 256: the cg_rownorm path
+  hp.verbose = 0
+  gen, dis = get_models(hp, None)
+  gan = get_algorithm(hp, gen, dis, None)
+  B, n = 8, gan.n_critic
+  rng = np.random.RandomState(0)
+  data = rng.uniform(0, 1, (64, 256, 16)).astype(np.float32)
+  batch = lambda i: data[8 * (i % 8):8 * (i % 8) + 8]
+  for i in range(6):
+    gan.train(batch(i))
+  st = gan._get_state(B)
+  old = st.get('graph')
+  assert old is not None
+  gan.validate(data[:6])
+  for i in range(3):
+    gan.train(batch(i), O.draw_randomness(hp, B, seed=50 + i))
+  assert st.get('graph') is old, 'the graphs captured before must be kept'
+  torch.cuda.synchronize()
+  s_local = gan._streams.local.get_state()
+  s_shared = gan._streams.shared.get_state()
+  gw = [torch.tensor(w) for w in gen.get_weights()]
+  dw = [torch.tensor(w) for w in dis.get_weights()]
+  out = gan.train(batch(3))
+  torch.cuda.synchronize()
+  assert st.get('graph') is old
+  gp = st['gp'].cpu().numpy()
+  loss = st['loss'].cpu().numpy()
+  assert np.isfinite(gp).all() and (gp < 5.0).all(), gp
+  assert np.isfinite([float(out[0]), float(out[1]), float(out[2])]).all()
+  # the draws of that replay, in its order: shifts of the n critic updates then
+  # the generator's (host stream); z of all updates, then alpha per update
+  gan._streams.local.set_state(s_local)
+  gan._streams.shared.set_state(s_shared)
+  shifts0 = gan._streams.shifts(3).numpy()
+  z0 = gan.get_noise(n * B)[:B].cpu().numpy()
+  alpha0 = gan._streams.alpha(B).cpu().numpy()
+  res = O.d_step_grads(gw, dw, torch.tensor(batch(3)), torch.tensor(z0),
+                       torch.tensor(alpha0), list(shifts0[:, 0]),
+                       list(shifts0[:, 1]), list(shifts0[:, 2]), hp,
+                       O.bf16_round, O.bf16_round)
+  np.testing.assert_allclose(gp[0], float(res['gp']), rtol=3e-2, atol=1e-4)
+  np.testing.assert_allclose(loss[0, 0], float(res['loss']), rtol=3e-2,
+                             atol=1e-2)

@@ -27,18 +27,24 @@ def _free_port():
   return p
 
 
-def _run_workers(tmp_path, backend):
+def _launch(tmp_path, backend, mode='train', script=None, args=()):
   env = dict(os.environ)
   env['DP_WORKER_OUT'] = str(tmp_path)
   env['DP_BACKEND'] = backend
+  env['DP_MODE'] = mode
   env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
          '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
          '--master-port', str(_free_port()),
-         os.path.join(ROOT, 'tests', 'dp_worker.py')]
+         script or os.path.join(ROOT, 'tests', 'dp_worker.py')] + list(args)
   out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True,
                        timeout=600)
   assert out.returncode == 0, out.stderr[-2000:]
+  return out
+
+
+def _run_workers(tmp_path, backend):
+  _launch(tmp_path, backend)
   recs = [json.load(open(os.path.join(str(tmp_path), 'rank%d.json' % r)))
           for r in (0, 1)]
   assert sorted(r['rank'] for r in recs) == [0, 1]
@@ -67,3 +73,85 @@ def test_two_rank_train_over_rccl(tmp_path):
     pytest.skip('needs one GPU per rank (found {})'.format(
         torch.cuda.device_count()))
   _run_workers(tmp_path, 'nccl')
+
+
+def _rel(a, b):
+  import numpy as np
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def test_data_parallel_equals_single_rank_on_the_global_batch(tmp_path):
+  """HIP data parallel == HIP single rank (VERDICT r2 'weak' 5): two ranks x
+  B/2 samples with their rows of the injected draws, gradients all-reduced and
+  scaled by 1/world, against ONE rank computing the global batch of B with the
+  same draws in this process.  Every per-sample quantity is computed by the
+  same kernels on the same bf16 values either way; what differs is the order
+  of f32 sums (two shards, other K' splits): the bar is 2e-3 relative."""
+  import numpy as np
+  import torch
+  import oracle as O
+  import dp_worker as W
+  from calciumgan_amd.gan.algorithms import get_algorithm
+  from calciumgan_amd.gan.models import get_models
+  _launch(tmp_path, 'gloo', mode='equiv')
+  dp = [np.load(os.path.join(str(tmp_path), 'equiv_rank%d.npz' % r))
+        for r in (0, 1)]
+  # both ranks hold the same reduced gradients
+  assert np.array_equal(dp[0]['d_grad'], dp[1]['d_grad'])
+  assert np.array_equal(dp[0]['g_grad'], dp[1]['g_grad'])
+  E = W.EQUIV
+  hp = O.make_hparams(E['L'], E['C'], E['U'], kernel_size=24, m=2,
+                      layer_norm=True)
+  hp.verbose = 0
+  gen, dis = get_models(hp, None)   # same seed: the workers' initial weights
+  gan = get_algorithm(hp, gen, dis, None)
+  real, rc, rg = W.equiv_inputs(hp, 2)
+  real_d = torch.tensor(real).to(gan.device)
+  gan._critic_compute(real_d, rc, slot=0)
+  st = gan._get_state(E['B'])
+  d_grad = dis.net.params.grad.cpu().numpy()
+  gp_loss = [float(st['gp'][0]), float(st['loss'][0, 0])]
+  gan._gen_compute(real_d, rg)
+  g_grad = gen.net.params.grad.cpu().numpy()
+  e_d, e_g = _rel(dp[0]['d_grad'], d_grad), _rel(dp[0]['g_grad'], g_grad)
+  print('\nDP(2 x %d) vs single rank (%d): critic grad rel %.2e, generator grad '
+        'rel %.2e, gp %.6f vs %.6f' % (E['B'] // 2, E['B'], e_d, e_g,
+                                       dp[0]['gp_loss'][0], gp_loss[0]))
+  assert np.linalg.norm(d_grad) > 0 and np.linalg.norm(g_grad) > 0
+  assert e_d < 2e-3 and e_g < 2e-3, (e_d, e_g)
+  np.testing.assert_allclose(dp[0]['gp_loss'], gp_loss, rtol=1e-3, atol=1e-5)
+
+
+def test_fp16_overflow_on_one_rank_skips_the_update_on_all(tmp_path):
+  """mixed_float16 + data parallel: the finite check sees the REDUCED gradients,
+  so an inf on one rank halves the loss scale and skips the Adam step on both
+  (and a clean step applies on both)."""
+  _launch(tmp_path, 'gloo', mode='overflow')
+  recs = [json.load(open(os.path.join(str(tmp_path), 'overflow_rank%d.json' % r)))
+          for r in (0, 1)]
+  for r in recs:
+    c, p = r['clean'], r['one_rank_inf']
+    assert c['applied'] == 1 and c['moved'] > 0 and c['finite'], r
+    assert c['scale_after'] == c['scale_before'], r
+    assert p['applied'] == 0 and p['moved'] == 0.0 and p['finite'], r
+    assert p['scale_after'] == p['scale_before'] / 2, r
+  assert recs[0] == recs[1]
+
+
+def test_bench_two_rank_command_path(tmp_path):
+  """The SCALE command path before an 8-GPU node exists: bench.py under
+  torch.distributed.run with 2 ranks (gloo, both on this box's one GPU), the
+  contract's JSON line from rank 0 only."""
+  out = _launch(tmp_path, 'gloo', script=os.path.join(ROOT, 'bench.py'),
+                args=['--gpus', '2', '--backend', 'gloo', '--steps', '3',
+                      '--warmup', '2', '--no_cpu_baseline', '--batch', '32'])
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, out.stdout[-2000:]
+  rec = json.loads(lines[0])
+  assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['warmup'] == 2
+  assert rec['config']['global_batch'] == 64
+  assert rec['config']['parallelism'] == 'dp2'
+  assert rec['scaling'] == 'weak' and rec['unit'] == 'samples/s'
+  assert rec['value'] > 0 and rec['ms_per_step'] > 0
+  assert 'roofline' in rec

@@ -98,3 +98,50 @@ def test_dg_metrics_report(tmp_path):
   fr, cov = cdm.get_data_statistics(hp, val)
   z = cdm.report(fr, fr, cov, cov)
   assert z['firing_rate']['rmse'] == 0 and z['covariance']['mse'] == 0
+
+
+def test_oasis_hand_worked_example():
+  """Algorithm 3 of Friedrich, Zhou & Paninski (2017) stepped through by hand
+  (pools (v, w, t, l); merge while v_i/w_i < g^l_{i-1} v_{i-1}/w_{i-1} + s_min):
+  y = [1, .2, .6, .1], g = .5.
+    s_min = 0:   t1: .5 > .2 -> merge: v 1.1, w 1.25 (value .88).  t2: .88 g^2 =
+                 .22 < .6 -> new pool.  t3: .6 g = .3 > .1 -> merge: v .65, w 1.25
+                 (value .52); .22 < .52 -> stop.
+                 c = [.88, .44, .52, .26], s = [0, 0, .30, 0].
+    s_min = .35: as above until the last test: .22 + .35 > .52 -> merge the two
+                 pools: v 1.1 + .65/4 = 1.2625, w 1.25 + 1.25/16 = 1.328125;
+                 c = 1.2625/1.328125 * [1, .5, .25, .125], no spike."""
+  y = np.array([1.0, 0.2, 0.6, 0.1])
+  c, s = spike_helper.oasis_ar1(y, 0.5, s_min=0.0)
+  np.testing.assert_allclose(c, [0.88, 0.44, 0.52, 0.26], atol=1e-12)
+  np.testing.assert_allclose(s, [0.0, 0.0, 0.30, 0.0], atol=1e-12)
+  c, s = spike_helper.oasis_ar1(y, 0.5, s_min=0.35)
+  c0 = 1.2625 / 1.328125
+  np.testing.assert_allclose(c, c0 * 0.5**np.arange(4), atol=1e-12)
+  np.testing.assert_allclose(s, 0.0, atol=1e-12)
+  c2, s2 = spike_helper.oasis_ar1_python(y, 0.5, s_min=0.35)
+  np.testing.assert_allclose(c2, c, atol=1e-12)
+
+
+def test_oasis_solves_its_defining_problem():
+  """OASIS with s_min = 0, lambda = 0 is an exact solver of the convex problem
+  the paper states (its Eq. 3): min_c 1/2 |c - y|^2  s.t.  s_t = c_t - g
+  c_{t-1} >= 0.  With c = K s (K lower-triangular Toeplitz of g^k) that is a
+  non-negative least-squares problem, solved here independently by
+  scipy.optimize.nnls -- a known answer that does not come from OASIS code."""
+  from scipy.optimize import nnls
+  rng = np.random.RandomState(5)
+  g = 0.95
+  for T in (40, 120):
+    sp = (rng.rand(T) < 0.08).astype(np.float64)
+    c = np.zeros(T)
+    for t in range(T):
+      c[t] = sp[t] + (g * c[t - 1] if t else 0.0)
+    y = c + 0.3 * rng.randn(T)
+    K = np.tril(g**np.subtract.outer(np.arange(T), np.arange(T)).clip(min=0))
+    s_ref, _ = nnls(K, y, maxiter=20 * T)
+    c_ref = K @ s_ref
+    c_hat, s_hat = spike_helper.oasis_ar1(y, g, s_min=0.0)
+    np.testing.assert_allclose(c_hat, c_ref, atol=1e-8)
+    # (s[0] is defined as 0 by the reference's convention; the rest agree)
+    np.testing.assert_allclose(s_hat[1:], s_ref[1:], atol=1e-8)

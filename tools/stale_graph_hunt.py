@@ -35,8 +35,6 @@ hp = O.make_hparams(256, 16, 8, m=2)
 hp.verbose = 0
 gen, dis = get_models(hp, None)
 gan = get_algorithm(hp, gen, dis, None)
-# test hook: keep the old graphs across eager steps (the state before the fix)
-gan._keep_graphs_across_eager = True
 rng = np.random.RandomState(0)
 data = torch.tensor(rng.uniform(0, 1, (64, 256, 16)).astype(np.float32),
                     device='cuda')
