@@ -503,9 +503,10 @@ __global__ __launch_bounds__(kThreads) void sumsq_kernel(
     atomicAdd(sumsq + b, part[0] + part[1] + part[2] + part[3]);
 }
 
-// (a kernel, not hipMemsetAsync: a memset NODE of a captured hipGraph wrote a
-// stale non-zero pattern when other work ran between two replays -- the
-// round-2 "stale graph" penalties of 1e25; tools/probe/graph_memset.hip)
+// (a kernel, not hipMemsetAsync: inside the captured step that call is a memset
+// NODE, and replayed after other work had run it no longer left zeros in front
+// of the atomics below -- the round-2 "stale graph" penalties of 1e25, DESIGN.md
+// section 8; tools/stale_graph_hunt.py memsetprobe)
 __global__ void zero_f32_kernel(float* v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = 0.f;

@@ -104,6 +104,27 @@ def generator_layers(hp):
   return layers
 
 
+# activation_fn (gan/models/utils.py:6-8): 'leakyrelu' -> LeakyReLU() (Keras
+# default alpha 0.3), any other name -> layers.Activation(name).  The kernels
+# implement the PIECEWISE-LINEAR ones as x -> max(x, alpha x): the fused
+# epilogues, the LeakyReLU' masks of every backward chain and -- the reason for
+# the restriction -- the hand-derived second backward of the gradient penalty,
+# which relies on the activation's second derivative being zero.
+PIECEWISE_LINEAR_ALPHA = {'leakyrelu': 0.3, 'relu': 0.0, 'linear': 1.0}
+
+
+def activation_alpha(hp):
+  """Slope for negative inputs of hparams.activation, or ValueError."""
+  name = getattr(hp, 'activation', 'leakyrelu')
+  if name not in PIECEWISE_LINEAR_ALPHA:
+    raise ValueError(
+        "calciumgan_amd: activation '{}' is not implemented (piecewise-linear "
+        'activations only: {}; a smooth activation adds a second-derivative '
+        'term to the gradient penalty that the kernel schedule does not '
+        'carry)'.format(name, ', '.join(sorted(PIECEWISE_LINEAR_ALPHA))))
+  return PIECEWISE_LINEAR_ALPHA[name]
+
+
 def validate_hparams(hp):
   """Shapes the HIP path supports; raises ValueError like the reference does
   for a non-integer noise width (calciumgan.py:17-18)."""
@@ -116,8 +137,7 @@ def validate_hparams(hp):
   if getattr(hp, 'batch_norm', False):
     raise ValueError('calciumgan_amd: batch_norm is not supported '
                      '(needs cross-rank statistics under data parallelism)')
-  if getattr(hp, 'activation', 'leakyrelu') != 'leakyrelu':
-    raise ValueError('calciumgan_amd: only activation=leakyrelu is implemented')
+  activation_alpha(hp)  # raises for activations the kernels do not cover
   w, _ = calculate_noise_shape(hp.signal_shape, hp.noise_dim, NUM_CONVS,
                                hp.strides)
   for lay in discriminator_layers(hp):

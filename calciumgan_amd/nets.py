@@ -207,7 +207,7 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
                seg_size=1, epilogue=_lib.EPI_NONE, out_f32=False, nphase=1,
                w_phase_stride=0, off_phase_step=0, yoff_phase_step=0,
                rowsumsq=None, w_parity_major=False, ln=None, out_shifts=None,
-               w_narrow_last=False):
+               w_narrow_last=False, alpha=LEAKY_ALPHA):
   d = ConvDesc()
   d.w_parity_major = int(bool(w_parity_major) and stride == 2)
   d.w_narrow_last = int(bool(w_narrow_last) and d.w_parity_major)
@@ -222,7 +222,7 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
   d.taps, d.stride, d.off, d.Lu = taps, stride, off, Lu
   d.N, d.Ly, d.Cy, d.y_stride, d.y_off = N, Ly, Cy, y_stride, y_off
   d.CK = CK
-  d.epilogue, d.out_f32, d.alpha = epilogue, int(out_f32), LEAKY_ALPHA
+  d.epilogue, d.out_f32, d.alpha = epilogue, int(out_f32), alpha
   d.nphase, d.w_phase_stride = nphase, w_phase_stride
   d.off_phase_step, d.yoff_phase_step = off_phase_step, yoff_phase_step
   n_tiles_n = (N + 63) // 64
@@ -595,6 +595,7 @@ class DiscriminatorNet(object):
     self.h_dtype = act_dtype()  # torch dtype of activations / operands
     geo.validate_hparams(hp)
     self.hp = hp
+    self.alpha = geo.activation_alpha(hp)  # x -> max(x, alpha x)
     self.device = device
     self.k = hp.kernel_size
     self.pl = geo.same_padding_left(self.k, hp.strides)
@@ -707,7 +708,7 @@ class _DisPlan(object):
                      2, -pl, lay.lout, lay.cout, lay.lout, lay.coutp, op.CK,
                      bias=bias, shifts=sh, seg_size=seg_size,
                      epilogue=_lib.EPI_LRELU, w_parity_major=op.parity_major,
-                     w_narrow_last=op.narrow_last))
+                     w_narrow_last=op.narrow_last, alpha=net.alpha))
       self.wgrad.append(
           _wgrad_desc(ws.act[i], ws.delta[i + 1], net.params.grad_views[2 * i],
                       nB, lay.lin, lay.cinp, lay.lout, lay.coutp, k, 2, -pl,
@@ -729,7 +730,8 @@ class _DisPlan(object):
         self.side[i] = torch.zeros(nB, m, lay.cinp, dtype=act_dtype(),
                                    device=dev)
         extra = dict(mask_src=ws.act[i], epilogue=_lib.EPI_MASK,
-                     out_shifts=(self.shifts[i - 1], seg_size, self.side[i], m))
+                     out_shifts=(self.shifts[i - 1], seg_size, self.side[i], m),
+                     alpha=net.alpha)
       self.dgrad.append((i,
                          _conv_desc(ws.delta[i + 1], op.buf,
                                     ws.delta[i] if fused else ws.e[i], nB,
@@ -783,7 +785,7 @@ class _DisPlan(object):
                      lay.coutp, op.CK, mask_src=seg_act, shifts=sh,
                      seg_size=n, epilogue=_lib.EPI_MASK,
                      w_parity_major=op.parity_major,
-                     w_narrow_last=op.narrow_last))
+                     w_narrow_last=op.narrow_last, alpha=net.alpha))
 
   # -- schedules ------------------------------------------------------------
   def forward(self):
@@ -804,7 +806,7 @@ class _DisPlan(object):
     last = net.layers[-1]
     _lib.call('cg_dense1_bwd', _p(net.dense_w), _p(self.coef), _p(ws.act[-1]),
               _p(ws.delta[-1]), self.nB, last.lout, last.cout, last.coutp,
-              self.seg_size, LEAKY_ALPHA, st)
+              self.seg_size, net.alpha, st)
     for i, d in self.dgrad:
       _run_conv(d, st)
       lay = net.layers[i - 1]
@@ -812,11 +814,11 @@ class _DisPlan(object):
         side = self.side[i]
         _lib.call('cg_unshuffle_fixup', _p(side), _p(ws.act[i]),
                   _p(ws.delta[i]), _p(self.shifts[i - 1]), self.nB, lay.lout,
-                  lay.coutp, self.seg_size, side.shape[1], LEAKY_ALPHA, st)
+                  lay.coutp, self.seg_size, side.shape[1], net.alpha, st)
       else:
         _lib.call('cg_unshuffle_mask', _p(ws.e[i]), _p(ws.act[i]),
                   _p(ws.delta[i]), _p(self.shifts[i - 1]), self.nB, lay.lout,
-                  lay.coutp, self.seg_size, LEAKY_ALPHA, st)
+                  lay.coutp, self.seg_size, net.alpha, st)
     if self.input_grad is not None:
       if self.sumsq is not None:
         self.sumsq.zero_()
@@ -856,6 +858,7 @@ class GeneratorNet(object):
     self.h_dtype = act_dtype()  # torch dtype of activations / operands
     self.w0 = geo.validate_hparams(hp)
     self.hp = hp
+    self.alpha = geo.activation_alpha(hp)  # x -> max(x, alpha x)
     self.device = device
     self.k = hp.kernel_size
     self.pl = geo.same_padding_left(self.k, hp.strides)
@@ -963,7 +966,7 @@ class _GenWorkspace(object):
     # ---- forward descriptors
     self.f_in = _conv_desc(self.z, net.w_in.buf, self.h[0], B, 1, nd, 1, 1, 0, 1,
                            w0 * nd, 1, w0 * nd, net.w_in.CK, bias=V[1],
-                           epilogue=_lib.EPI_LRELU)
+                           epilogue=_lib.EPI_LRELU, alpha=net.alpha)
     self.f_conv = []
     self.f_conv_fwd_only = []  # G(z) of a critic update: nothing kept for backward
     self.ln_fused = []
@@ -982,7 +985,7 @@ class _GenWorkspace(object):
                      off_phase_step=net.fwd_offs[1] - net.fwd_offs[0],
                      yoff_phase_step=1,
                      ln=(V[ic + 2], V[ic + 3], self.h[i + 1], self.mean[i + 1],
-                         self.rstd[i + 1]) if fuse else None))
+                         self.rstd[i + 1]) if fuse else None, alpha=net.alpha))
       self.f_conv_fwd_only.append(
           _conv_desc(self.h[i], op.buf, dst, B, lay.lin, lay.cinp, k // 2, 1,
                      net.fwd_offs[0], lay.lin, lay.cout, lay.lout, lay.coutp,
@@ -990,7 +993,8 @@ class _GenWorkspace(object):
                      w_phase_stride=op.elems,
                      off_phase_step=net.fwd_offs[1] - net.fwd_offs[0],
                      yoff_phase_step=1,
-                     ln=(V[ic + 2], V[ic + 3], self.h[i + 1], None, None))
+                     ln=(V[ic + 2], V[ic + 3], self.h[i + 1], None, None),
+                     alpha=net.alpha)
           if fuse else self.f_conv[-1])
     # (fallback for outputs wider than 128 channels; the streaming Dense of
     # forward() otherwise -- self.fake then has the narrower pitch Cf)
@@ -1042,7 +1046,7 @@ class _GenWorkspace(object):
         _lib.call('cg_ln_lrelu_fwd', _p(self.ypre[i + 1]), _p(V[ic + 2]),
                   _p(V[ic + 3]), _p(self.h[i + 1]), _p(self.mean[i + 1]),
                   _p(self.rstd[i + 1]), self.B * lay.lout, lay.cout, lay.coutp,
-                  LN_EPS, LEAKY_ALPHA, st)
+                  LN_EPS, net.alpha, st)
     if net.streaming_out:
       # HBM-bound per-timestep Dense (+ sigmoid): the streaming kernel
       _lib.call('cg_dense_rows', _p(self.h[-1]), _p(net.w_out.buf),
@@ -1078,16 +1082,16 @@ class _GenWorkspace(object):
                   _p(self.ypre[i + 1]), _p(self.mean[i + 1]),
                   _p(self.rstd[i + 1]), _p(V[ic + 2]), _p(self.dy[i + 1]),
                   _p(G[ic + 2]), _p(G[ic + 3]), _p(G[ic + 1]), n, lay.cout,
-                  lay.coutp, LEAKY_ALPHA, st)
+                  lay.coutp, net.alpha, st)
       else:
         _lib.call('cg_lrelu_bwd', _p(self.dh[i + 1]), _p(self.h[i + 1]),
-                  _p(self.dy[i + 1]), n * lay.coutp, LEAKY_ALPHA, st)
+                  _p(self.dy[i + 1]), n * lay.coutp, net.alpha, st)
         _lib.call('cg_colsum', _p(self.dy[i + 1]), _p(G[ic + 1]), n, lay.cout,
                   lay.coutp, st)
       _run_conv(self.b_dgrad[i], st)
     nflat = net.w0 * net.nd
     _lib.call('cg_lrelu_bwd', _p(self.dh[0]), _p(self.h[0]), _p(self.dy[0]),
-              self.B * nflat, LEAKY_ALPHA, st)
+              self.B * nflat, net.alpha, st)
     _run_wgrad(self.b_in_wgrad, st)
     _lib.call('cg_colsum', _p(self.dy[0]), _p(G[1]), self.B, nflat, nflat, st)
     # the conv-transpose weight gradients read h[i] / dy[i+1], which the chain

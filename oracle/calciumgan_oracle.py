@@ -25,7 +25,8 @@ import torch.nn.functional as F
 
 __all__ = [
     'make_hparams', 'calculate_noise_shape', 'same_padding', 'conv1d_same',
-    'conv1d_transpose_same', 'layer_norm', 'leaky_relu', 'phase_shuffle',
+    'conv1d_transpose_same', 'layer_norm', 'leaky_relu', 'activation_fn',
+    'phase_shuffle',
     'phase_shuffle_index', 'init_generator', 'init_discriminator',
     'count_params', 'generator_forward', 'discriminator_forward',
     'interpolation', 'gradient_penalty', 'discriminator_loss',
@@ -222,6 +223,25 @@ def leaky_relu(x, alpha=LEAKY_ALPHA):
   return torch.where(x > 0, x, alpha * x)
 
 
+def activation_fn(name):
+  """gan/models/utils.py:6-8: LeakyReLU() for 'leakyrelu', else
+  layers.Activation(name) (Keras activation names)."""
+  table = {
+      'leakyrelu': leaky_relu,
+      'relu': torch.relu,
+      'linear': lambda x: x,
+      'tanh': torch.tanh,
+      'sigmoid': torch.sigmoid,
+      'elu': torch.nn.functional.elu,
+      'selu': torch.nn.functional.selu,
+      'softplus': torch.nn.functional.softplus,
+      'swish': torch.nn.functional.silu,
+  }
+  if name not in table:
+    raise ValueError('unknown activation {}'.format(name))
+  return table[name]
+
+
 def phase_shuffle_index(w, shift):
   """Source index map of PhaseShuffle (calciumgan.py:117-138) for one shift:
   out[t] = x[idx[t]].  shift>0: reflect-pad right by shift, take
@@ -315,8 +335,9 @@ def generator_forward(weights, z, hp, q=_ident, wq=_ident):
   shape = calculate_noise_shape(hp.signal_shape, hp.noise_dim, NUM_CONVS,
                                 hp.strides)
   it = iter(weights)
+  act = activation_fn(getattr(hp, 'activation', 'leakyrelu'))
   dw, db = next(it), next(it)
-  x = q(leaky_relu(q(z) @ wq(dw) + db))  # :32-33
+  x = q(act(q(z) @ wq(dw) + db))  # :32-33
   x = x.reshape(z.shape[0], shape[0], shape[1])  # :34
   for _ in range(NUM_CONVS):
     cw, cb = next(it), next(it)
@@ -324,7 +345,7 @@ def generator_forward(weights, z, hp, q=_ident, wq=_ident):
     if hp.layer_norm:
       g, b = next(it), next(it)
       x = layer_norm(x, g, b)
-    x = q(leaky_relu(x))
+    x = q(act(x))
   ow, ob = next(it), next(it)
   x = x @ wq(ow) + ob  # Dense on the last axis, :96
   if hp.normalize:
@@ -337,10 +358,11 @@ def discriminator_forward(weights, x, shifts, hp, q=_ident, wq=_ident):
   shifts: 4 ints, the PhaseShuffle draws after layers 1-4 of THIS call."""
   assert len(shifts) == NUM_CONVS - 1
   it = iter(weights)
+  act = activation_fn(getattr(hp, 'activation', 'leakyrelu'))
   x = q(x)
   for layer in range(NUM_CONVS):
     cw, cb = next(it), next(it)
-    x = q(leaky_relu(conv1d_same(x, wq(cw), cb, hp.strides)))
+    x = q(act(conv1d_same(x, wq(cw), cb, hp.strides)))
     if layer < NUM_CONVS - 1:
       x = phase_shuffle(x, shifts[layer])
   dw, db = next(it), next(it)

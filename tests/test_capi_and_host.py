@@ -235,3 +235,25 @@ def test_ck_choice_fits_lds():
                                (32, 1, 1, 1), (104, 1, 1, 2048)]:
     ck = nets._ck_for(cx, stride, taps, lu)
     assert cx % ck == 0 and ck % 8 == 0 and ck >= 32
+
+
+def test_smooth_activations_are_rejected_with_the_reason():
+  """activation_fn (gan/models/utils.py:6-8) accepts any Keras name; the HIP
+  schedule covers the piecewise-linear ones and says why it refuses the rest."""
+  import pytest
+  from calciumgan_amd import geometry as geo
+  import oracle as O
+  hp = O.make_hparams(256, 16, 8)
+  for name, alpha in (('leakyrelu', 0.3), ('relu', 0.0), ('linear', 1.0)):
+    hp.activation = name
+    assert geo.activation_alpha(hp) == alpha
+    geo.validate_hparams(hp)
+  hp.activation = 'tanh'
+  with pytest.raises(ValueError, match='piecewise-linear'):
+    geo.validate_hparams(hp)
+  # the oracle itself follows activation_fn for every name
+  import torch
+  x = torch.tensor([-1.0, 0.0, 2.0])
+  assert torch.equal(O.activation_fn('relu')(x), torch.tensor([0.0, 0.0, 2.0]))
+  assert torch.allclose(O.activation_fn('leakyrelu')(x), torch.tensor([-0.3, 0.0, 2.0]))
+  assert torch.allclose(O.activation_fn('tanh')(x), torch.tanh(x))

@@ -510,3 +510,43 @@ def test_old_graphs_replay_correctly_after_validate_and_eager_steps():
   np.testing.assert_allclose(gp[0], float(res['gp']), rtol=3e-2, atol=1e-4)
   np.testing.assert_allclose(loss[0, 0], float(res['loss']), rtol=3e-2,
                              atol=1e-2)
+
+
+@pytest.mark.parametrize('activation', ['relu', 'linear'])
+def test_other_piecewise_linear_activations(activation):
+  """hparams.activation (gan/models/utils.py:6-8): besides 'leakyrelu' the
+  kernels cover the other piecewise-linear Keras activations -- x -> max(x,
+  alpha x) with alpha 0 ('relu') or 1 ('linear') in every fused epilogue, every
+  backward mask and the penalty's tangent chain.  One critic update and one
+  generator update against the oracle with the same activation."""
+  from calciumgan_amd.gan.algorithms import get_algorithm
+  from calciumgan_amd.gan.models import get_models
+  L, C, U, B = 128, 6, 8, 3
+  hp = O.make_hparams(L, C, U, kernel_size=24, m=2)
+  hp.activation = activation
+  hp.verbose = 0
+  gen, dis = get_models(hp, None)
+  gan = get_algorithm(hp, gen, dis, None)
+  assert dis.net.alpha == {'relu': 0.0, 'linear': 1.0}[activation]
+  rng = np.random.RandomState(5)
+  real = rng.uniform(0, 1, (B, L, C)).astype(np.float32)
+  r = O.draw_randomness(hp, B, seed=21)
+  rc = r['critic'][0]
+  emu = _oracle_critic(hp, gen, dis, real, rc, O.bf16_round)
+  f32 = _oracle_critic(hp, gen, dis, real, rc, lambda x: x)
+  loss, gp = gan._train_discriminator(real, rc, slot=0)
+  torch.cuda.synchronize()
+  np.testing.assert_allclose(float(gp), float(emu['gp']), rtol=1e-2, atol=1e-4)
+  np.testing.assert_allclose(float(loss), float(emu['loss']), rtol=1e-2, atol=1e-3)
+  _check_grads(dis.net.params.grad_views, emu['grads'], f32['grads'],
+               'critic ' + activation)
+  gw = [torch.tensor(w) for w in gen.get_weights()]
+  dw = [torch.tensor(w) for w in dis.get_weights()]
+  g_emu = O.g_step_grads(gw, dw, torch.tensor(r['gen']['z']), r['gen']['shifts'],
+                         hp, O.bf16_round, O.bf16_round)
+  g_f32 = O.g_step_grads(gw, dw, torch.tensor(r['gen']['z']), r['gen']['shifts'],
+                         hp, lambda x: x, lambda x: x)
+  gan._gen_compute(gan._to_device(real), r['gen'])
+  torch.cuda.synchronize()
+  _check_grads(gen.net.params.grad_views, g_emu['grads'], g_f32['grads'],
+               'generator ' + activation)

@@ -34,8 +34,12 @@ for fam, c in res.items():
     out[fam] = dict(
         launches_profiled=c['SQ_WAVE_CYCLES'][0],
         avg_launch_us_under_profiler=dur[fam][1] / dur[fam][0],
-        # SQ_VALU_MFMA_BUSY_CYCLES counts per-SIMD cycles, SQ_BUSY_CU_CYCLES per CU: 4 SIMDs
+        # SQ_VALU_MFMA_BUSY_CYCLES counts per-SIMD cycles, SQ_BUSY_CU_CYCLES per CU: 4 SIMDs.
+        # "busy_cu": of the cycles in which a CU held waves; "wall": of the launch's
+        # wall clock on all 1024 SIMDs (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
         mfma_pipe_busy_frac=m['SQ_VALU_MFMA_BUSY_CYCLES'] / (4.0 * m['SQ_BUSY_CU_CYCLES']),
+        mfma_pipe_busy_frac_wall=m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0),
+        cu_busy_frac_wall=m['SQ_BUSY_CU_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8.0 * 256.0),
         wave_cycles_frac=dict(issuing=m['SQ_ACTIVE_INST_ANY'] / wc, waitcnt_or_barrier=m['SQ_WAIT_ANY'] / wc,
                               issue_stalled=m['SQ_WAIT_INST_ANY'] / wc),
         per_mfma=dict(valu=(m['SQ_INSTS_VALU'] - m['SQ_INSTS_MFMA']) / m['SQ_INSTS_MFMA'], salu=m['SQ_INSTS_SALU'] / m['SQ_INSTS_MFMA'],
