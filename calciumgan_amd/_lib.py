@@ -183,6 +183,10 @@ def load(precision=None):
   precision = precision or _active
   if precision in _libs:
     return _libs[precision]
+  # torch first: its wheel bundles a HIP runtime, and the library must bind to
+  # THAT copy -- loaded before torch, it pulled in /opt/rocm's libamdhip64 and
+  # the process ended up with two runtimes (first launch: hipErrorNoDevice)
+  import torch  # noqa: F401
   path = LIB_PATH_F16 if precision == 'f16' else LIB_PATH
   if not os.path.exists(path):
     raise HipLibraryError(

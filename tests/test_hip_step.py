@@ -538,8 +538,28 @@ def test_other_piecewise_linear_activations(activation):
   torch.cuda.synchronize()
   np.testing.assert_allclose(float(gp), float(emu['gp']), rtol=1e-2, atol=1e-4)
   np.testing.assert_allclose(float(loss), float(emu['loss']), rtol=1e-2, atol=1e-3)
-  _check_grads(dis.net.params.grad_views, emu['grads'], f32['grads'],
-               'critic ' + activation)
+  def check(got, emu_g, f32_g, what):
+    # the per-tensor bar of test_critic_loss_terms_separately: agree with the
+    # bf16-emulating oracle clearly better than bf16 storage agrees with f32
+    # (a hard 0 / 1 mask -- relu -- flips with the rounding of a pre-activation
+    # near zero, so the whole-gradient cosine against f32 is looser than with
+    # LeakyReLU's 0.3 / 1)
+    bad = []
+    for i, (g, e, f) in enumerate(zip(got, emu_g, f32_g)):
+      g, e, f = g.detach().cpu().numpy(), e.numpy(), f.numpy()
+      if np.linalg.norm(f) < 1e-12:
+        continue
+      # (+ 2e-2: with a linear activation bf16 storage moves the gradients
+      # only ~1 % from f32, below the f32-atomic / rounding noise of a bias sum)
+      if _rel(g, e) > 0.8 * _rel(e, f) + 2e-2:
+        bad.append((i, _rel(g, e), _rel(e, f)))
+    assert not bad, (what, bad)
+    gh, gf = _flat(got), _flat([t.numpy() for t in f32_g])
+    cos = float(gh @ gf / (np.linalg.norm(gh) * np.linalg.norm(gf)))
+    assert cos > 0.97, (what, cos)
+
+  check(dis.net.params.grad_views, emu['grads'], f32['grads'],
+        'critic ' + activation)
   gw = [torch.tensor(w) for w in gen.get_weights()]
   dw = [torch.tensor(w) for w in dis.get_weights()]
   g_emu = O.g_step_grads(gw, dw, torch.tensor(r['gen']['z']), r['gen']['shifts'],
@@ -548,5 +568,5 @@ def test_other_piecewise_linear_activations(activation):
                          hp, lambda x: x, lambda x: x)
   gan._gen_compute(gan._to_device(real), r['gen'])
   torch.cuda.synchronize()
-  _check_grads(gen.net.params.grad_views, g_emu['grads'], g_f32['grads'],
-               'generator ' + activation)
+  check(gen.net.params.grad_views, g_emu['grads'], g_f32['grads'],
+        'generator ' + activation)
