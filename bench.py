@@ -58,8 +58,11 @@ def algorithmic_flops(hp):
   # the generator's last Dense runs in the streaming cg_dense_rows kernel
   # (HBM-bound, not part of the swconv family) whenever its shape allows
   f_dense = 2.0 * hp.signal_shape[0] * hp.num_channels * hp.num_channels
-  streaming = geo.pitch(hp.num_channels) <= 128
-  dense_rows = (n + 1) * f_dense if streaming else 0.0
+  cp = geo.pitch(hp.num_channels)
+  streaming = geo.dense_streams(cp)
+  # ((n + 1) forwards; + the input gradient dh = dz W^T of the generator update,
+  # streaming for pitches >= 128)
+  dense_rows = ((n + 1) + (1 if cp >= 128 else 0)) * f_dense if streaming else 0.0
   swconv = n * (f_g + 7 * f_d - 2 * f_d1) + 2 * f_g + 2 * f_d - dense_rows
   wgrad = n * 3 * f_d + f_g
   total = (n + 3) * f_g + (10 * n + 2) * f_d - 2 * n * f_d1
@@ -106,7 +109,8 @@ def algorithmic_bytes_swconv(hp, B, batched_g=False):
     return nb * (lay.lout * lay.coutp * 2 + lay.lin * lay.cinp * 2) + \
         k * lay.coutp * lay.cin * 2
 
-  streaming = cp <= 128  # last Dense in cg_dense_rows, not a swconv launch
+  streaming = geo.dense_streams(cp)  # last Dense in cg_dense_rows, not a swconv launch
+  streaming_dgrad = streaming and cp >= 128  # ... and its input gradient
 
   def g_forward(keep):
     t = B * (nd * 2 + w0 * nd * 2) + nd * w0 * nd * 2
@@ -115,7 +119,7 @@ def algorithmic_bytes_swconv(hp, B, batched_g=False):
       t += B * L * (cp * 2 + cp * 4) + cp * C * 2
     return t
 
-  g_bwd = B * L * (cp * 2 + cp * 2) + cp * C * 2
+  g_bwd = 0 if streaming_dgrad else B * L * (cp * 2 + cp * 2) + cp * C * 2
   g_bwd += sum(convT_dgrad(B, l) for l in g_l)
   d_fwd = lambda nb: sum(conv(nb, l) for l in d_l)
   fusable = lambda l: 2 * max(1, hp.m) + 1 <= l.lin
@@ -127,6 +131,8 @@ def algorithmic_bytes_swconv(hp, B, batched_g=False):
       dgrad(B, d_l[0]) + g_bwd
   g_launches = 6 if streaming else 7
   launches = n * (g_launches + 5 + 4 + 1 + 5) + (g_launches + 5 + 4 + 1 + 6)
+  if streaming_dgrad:
+    launches -= 1
   total = n * critic + gen
   if batched_g and n > 1:
     launches -= (n - 1) * g_launches

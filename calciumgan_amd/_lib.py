@@ -108,6 +108,7 @@ SIGNATURES = {
     'cg_swconv': [C.POINTER(ConvDesc), c_vp],
     'cg_swconv_check': [C.POINTER(ConvDesc)],
     'cg_dense_rows': [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_vp],
+    'cg_dense_rows_act': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],
     'cg_packed_elems': [c_i, c_i, c_i, c_i],
     'cg_pack_weights': [C.POINTER(PackDesc), c_vp],
     'cg_pack_plan_bytes': [c_i, c_ll],

@@ -126,16 +126,242 @@ __global__ __launch_bounds__(kDrThreads, 2) void dense_rows_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Wide form: K and / or N beyond 128 (BASELINE configs[4]: 512 -> 512 per
+// timestep over 2 M rows -- as a cg_swconv launch it ran at 0.2 PFLOP/s, 19 % of
+// that configuration's step).  W no longer fits a wave's registers, so a
+// workgroup keeps ONE 128-column panel of it in LDS (K x 128 bf16 = 128 KB at K
+// = 512, rows 16 bytes longer than a power of two: conflict-free ds_read_b128)
+// for its whole life and streams 32-row blocks through it: the x fragments of a
+// block (2 x K/32 16-byte loads per lane, MFMA layout, straight from global
+// memory) are double-buffered in registers -- the next block's loads fly during
+// this block's 16 K MFMA cycles --, every W fragment read from LDS feeds two
+// MFMAs (the block's two 16-row halves: 128 B/clk/CU of LDS at full matrix rate).
+// The weights are the MFMA's A operand, so a lane's accumulator registers are
+// consecutive columns of one row and v_permlane16_swap makes them eight: the
+// epilogue stores 32 (f32) or 16 (bf16) contiguous bytes per lane with no LDS.
+// One workgroup per CU (4 waves, one per SIMD, ~340 registers each); the
+// workgroups that walk the same rows through the N / 128 panels have ids
+// congruent mod 8 (same XCD, same time: x comes from HBM once).
+constexpr int kWideThreads = 256;
+constexpr int kWideCols = 128;
+
+struct DenseWideArgs {
+  const uint16_t* x;    // bf16 [rows][Cx]
+  const uint16_t* w;    // packed operand (taps 1, CK 32): [Npad][Cx/32][16][8]
+  const float* bias;    // f32 [N] or null
+  void* y;              // f32 or bf16 [rows][Cy]
+  long long rows;
+  int Cx, N, Cy, epilogue, out_act, panels;
+};
+
+template <int KSTEPS>
+__global__ __launch_bounds__(kWideThreads, 1) void dense_rows_wide_kernel(
+    DenseWideArgs a) {
+  constexpr int kRowB = KSTEPS * 64 + 16;  // LDS bytes per W column (k-major)
+  extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r16 = lane & 15;
+  const int g = lane >> 4;
+  // workgroup -> (panel, row group): ids congruent mod 8 share an XCD
+  const int xcd = blockIdx.x & 7;
+  const int j = blockIdx.x >> 3;
+  const int panel = j % a.panels;
+  const int rgroup = (j / a.panels) * 8 + xcd;
+  const int ngroups = (int)(gridDim.x / 8 / a.panels) * 8;
+  const int n0 = panel * kWideCols;
+  // the panel: column n0 + c, K-step ks, k-group gg -> 16 bytes
+  for (int i = tid; i < kWideCols * KSTEPS * 4; i += kWideThreads) {
+    const int c = i / (KSTEPS * 4);
+    const int ks = (i / 4) % KSTEPS;
+    const int gg = i & 3;
+    const uint4 v = *reinterpret_cast<const uint4*>(
+        a.w + (((long long)(n0 + c) * KSTEPS + ks) * 16 + gg) * 8);
+    *reinterpret_cast<uint4*>(wl + c * kRowB + (ks * 4 + gg) * 16) = v;
+  }
+  __syncthreads();
+  // lane's eight output columns per 32-column pair p (after the lane swap):
+  // block 2p + (g & 1), columns 8 (g >> 1) .. + 7
+  const int cq = (g & 1) * 16 + (g >> 1) * 8;
+  float bv[4][8];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = n0 + p * 32 + cq + e;
+      bv[p][e] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+    }
+  const bool sig = a.epilogue == CG_EPI_SIGMOID;
+  const int woff0 = r16 * kRowB + g * 16;
+
+  const long long nblk = (a.rows + 31) / 32;
+  const long long stride = (long long)ngroups * 4;
+  long long blk = (long long)rgroup * 4 + wave;
+  // (unconditional loads from a clamped row: with a predicate around them the
+  // compiler cannot count them and waits for the NEXT block's loads -- vmcnt(0)
+  // -- before computing this one; rows past the end are never stored)
+  auto load_x = [&](long long b, act8 (&dst)[2][KSTEPS]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      long long row = b * 32 + h * 16 + r16;
+      row = row < a.rows ? row : a.rows - 1;
+      const uint16_t* src = a.x + row * a.Cx + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+        dst[h][ks] = *reinterpret_cast<const act8*>(src + ks * 32);
+    }
+  };
+  auto compute = [&](long long b, const act8 (&xf)[2][KSTEPS]) {
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) acc[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (opaque per block: the W fragments are the same for every block, and
+    // hoisted out of the block loop all 8 K of them would sit in registers)
+    // (the OFFSET is laundered, not the pointer: a laundered pointer is generic,
+    // and its loads became flat_load + vmcnt(0) waits that also drained the x
+    // prefetch)
+    int woff = woff0;
+    asm volatile("" : "+v"(woff));
+    const unsigned char* wrow = wl + woff;
+    // W fragments double-buffered by K-step: the eight reads of step ks + 1 go
+    // out before the sixteen MFMAs of step ks, so their LDS latency sits behind
+    // 256 matrix-pipe cycles (one wave per SIMD: nothing else would hide it).
+    // The scheduling barriers keep the compiler from sinking the reads back to
+    // their first use.
+    act8 wa[8], wb[8];
+    auto ldw = [&](act8 (&d)[8], int ks) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+        d[nt] = *reinterpret_cast<const act8*>(wrow + nt * 16 * kRowB + ks * 64);
+    };
+    auto mm = [&](const act8 (&w)[8], int ks) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        acc[0][nt] = cg_mfma_16x16x32(w[nt], xf[0][ks], acc[0][nt], 0, 0, 0);
+        acc[1][nt] = cg_mfma_16x16x32(w[nt], xf[1][ks], acc[1][nt], 0, 0, 0);
+      }
+    };
+    static_assert(KSTEPS % 2 == 0, "K-steps are walked in pairs");
+    ldw(wa, 0);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks += 2) {
+      ldw(wb, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(wa, ks);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 2 < KSTEPS) ldw(wa, ks + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(wb, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long long m = b * 32 + h * 16 + r16;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(
+              __float_as_uint(acc[h][2 * p][r]),
+              __float_as_uint(acc[h][2 * p + 1][r]), false, false);
+          v[r] = __uint_as_float(sw[0]);
+          v[4 + r] = __uint_as_float(sw[1]);
+        }
+        const int n = n0 + p * 32 + cq;
+        if (m < a.rows && n < a.Cy) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float t = v[e] + bv[p][e];
+            const float sg = 1.f / (1.f + __expf(-t));
+            v[e] = (n + e < a.N) ? (sig ? sg : t) : 0.f;  // padding stays zero
+          }
+          if (a.out_act) {
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.y) +
+                                      m * a.Cy + n) =
+                make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]),
+                           pack2act(v[4], v[5]), pack2act(v[6], v[7]));
+          } else {
+            float* dst = reinterpret_cast<float*>(a.y) + m * a.Cy + n;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          }
+        }
+      }
+    }
+  };
+  act8 xf0[2][KSTEPS], xf1[2][KSTEPS];
+  load_x(blk, xf0);
+  while (blk < nblk) {
+    load_x(blk + stride, xf1);
+    compute(blk, xf0);
+    blk += stride;
+    if (blk >= nblk) break;
+    load_x(blk + stride, xf0);
+    compute(blk, xf1);
+    blk += stride;
+  }
+}
+
+template <int KSTEPS>
+int launch_dense_wide(const DenseWideArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)kWideCols * (KSTEPS * 64 + 16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&dense_rows_wide_kernel<KSTEPS>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  // one workgroup per CU: 256 = 8 XCDs x (32 / panels) row groups x panels
+  const int per_xcd = 32 / a.panels * a.panels;
+  hipLaunchKernelGGL(dense_rows_wide_kernel<KSTEPS>, dim3(8 * per_xcd),
+                     dim3(kWideThreads), lds, s, a);
+  CG_LAUNCH_CHECK();
+}
+
+int dense_rows_wide(const void* x, const void* w, const float* bias, void* y,
+                    long long rows, int Cx, int N, int Cy, int epilogue,
+                    int out_act, hipStream_t s) {
+  if (Cx % 32 || N < 1 || Cy < N || Cy % 8) return CG_EINVAL;
+  DenseWideArgs a;
+  a.x = reinterpret_cast<const uint16_t*>(x);
+  a.w = reinterpret_cast<const uint16_t*>(w);
+  a.bias = bias;
+  a.y = y;
+  a.rows = rows;
+  a.Cx = Cx; a.N = N; a.Cy = Cy; a.epilogue = epilogue; a.out_act = out_act;
+  // (the packed operand is padded to 128 columns: whole panels are readable)
+  a.panels = (N + kWideCols - 1) / kWideCols;
+  if (a.panels > 32) return CG_EINVAL;
+  switch (Cx / 32) {
+    case 4: return launch_dense_wide<4>(a, s);
+    case 8: return launch_dense_wide<8>(a, s);
+    case 12: return launch_dense_wide<12>(a, s);
+    case 16: return launch_dense_wide<16>(a, s);
+    default: return CG_EINVAL;
+  }
+}
+
 }  // namespace
 
 extern "C" int cg_dense_rows(const void* x, const void* w, const float* bias,
                              float* y, long long rows, int Cx, int N, int Cy,
                              int epilogue, void* stream) {
   if (!x || !w || !y || rows < 1) return CG_EINVAL;
+  if (epilogue != CG_EPI_NONE && epilogue != CG_EPI_SIGMOID) return CG_EINVAL;
+  if (Cx > 128 || N > 128)  // W beyond a wave's registers: the LDS-panel form
+    return dense_rows_wide(x, w, bias, y, rows, Cx, N, Cy, epilogue, 0,
+                           (hipStream_t)stream);
   if (Cx % 32 || Cx < 32 || Cx > 128 || N < 1 || N > 128 || Cy < N || Cy > 128 ||
       Cy % 4)
     return CG_EINVAL;
-  if (epilogue != CG_EPI_NONE && epilogue != CG_EPI_SIGMOID) return CG_EINVAL;
   DenseRowsArgs a;
   a.x = reinterpret_cast<const uint16_t*>(x);
   a.w = reinterpret_cast<const uint16_t*>(w);
@@ -155,4 +381,15 @@ extern "C" int cg_dense_rows(const void* x, const void* w, const float* bias,
     default: hipLaunchKernelGGL(dense_rows_kernel<4>, grid, block, 0, s, a); break;
   }
   CG_LAUNCH_CHECK();
+}
+
+// The same contraction with an activation-typed (bf16 / fp16) output and no
+// epilogue: the input gradient of the per-timestep Dense, dh = dz W^T (w = the
+// transposed packed operand).  LDS-panel form for every size.
+extern "C" int cg_dense_rows_act(const void* x, const void* w, void* y,
+                                 long long rows, int Cx, int N, int Cy,
+                                 void* stream) {
+  if (!x || !w || !y || rows < 1) return CG_EINVAL;
+  return dense_rows_wide(x, w, nullptr, y, rows, Cx, N, Cy, CG_EPI_NONE, 1,
+                         (hipStream_t)stream);
 }

@@ -71,6 +71,14 @@ def lds_bytes(CK, stride, taps, Lu, TM, TN=64, mfma_rows=16,
   return round_up(a, 16) + _LDS_B * (TN // 64)
 
 
+def dense_streams(cp):
+  """Channel pitches whose per-timestep Dense runs on the streaming kernels
+  (cg_dense_rows / cg_dense_rows_act) instead of an LDS-staged cg_swconv
+  launch: W in registers up to 128, one 128-column panel of W in LDS for 256,
+  384, 512."""
+  return cp <= 128 or cp in (256, 384, 512)
+
+
 ConvLayer = namedtuple('ConvLayer', 'cin cout lin lout cinp coutp')
 
 

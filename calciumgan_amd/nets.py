@@ -922,7 +922,10 @@ class GeneratorNet(object):
     # the f32 output (B, L, Cf): the streaming Dense writes rows of C rounded
     # up to 8 channels (102 -> 104: 19 % fewer bytes than the bf16 pitch 128 for
     # it and for every pass that reads it); the swconv fallback keeps Cp
-    self.streaming_out = self.Cp <= 128 and ck == 32
+    self.streaming_out = geo.dense_streams(self.Cp) and ck == 32
+    # its input gradient dh = dz W^T streams too (the LDS-panel form: pitches of
+    # 128 and up)
+    self.streaming_out_dgrad = self.streaming_out and self.Cp >= 128
     self.Cf = (self.C + 7) // 8 * 8 if self.streaming_out else self.Cp
     self._pack_plan = PackPlan(
         [self.w_in, self.w_out, self.w_out_t] + self.w_fwd + self.w_dgrad,
@@ -1007,9 +1010,9 @@ class _GenWorkspace(object):
       return
     # ---- backward descriptors
     G = net.params.grad_views
-    self.b_out_dgrad = _conv_desc(self.dz, net.w_out_t.buf, self.dh[-1], B,
-                                  net.L, net.Cp, 1, 1, 0, net.L, net.C, net.L,
-                                  net.Cp, net.w_out_t.CK)
+    self.b_out_dgrad = None if net.streaming_out_dgrad else _conv_desc(
+        self.dz, net.w_out_t.buf, self.dh[-1], B, net.L, net.Cp, 1, 1, 0, net.L,
+        net.C, net.L, net.Cp, net.w_out_t.CK)
     self.b_out_wgrad = _wgrad_desc(self.h[-1], self.dz, G[net.idx_out], B,
                                    net.L, net.Cp, net.L, net.Cp, 1, 1, 0, net.C,
                                    net.C)
@@ -1073,7 +1076,11 @@ class _GenWorkspace(object):
     _run_wgrad(self.b_out_wgrad, st)
     _lib.call('cg_colsum', _p(self.dz), _p(G[net.idx_out + 1]), rows, net.C,
               net.Cp, st)
-    _run_conv(self.b_out_dgrad, st)
+    if net.streaming_out_dgrad:
+      _lib.call('cg_dense_rows_act', _p(self.dz), _p(net.w_out_t.buf),
+                _p(self.dh[-1]), rows, net.Cp, net.C, net.Cp, st)
+    else:
+      _run_conv(self.b_out_dgrad, st)
     for i in range(len(net.layers) - 1, -1, -1):
       lay, ic = net.layers[i], net.idx_conv[i]
       n = self.B * lay.lout

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 13
+#define CG_ABI_VERSION 14
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -189,11 +189,20 @@ int cg_swconv_check(const cg_conv_desc* d);
  * layers.Dense + sigmoid, calciumgan.py:96-101; HBM-bound):
  *   y[r, n] = epi(bias[n] + sum_c x[r, c] * W[c][n]),  y[r, n >= N] = 0
  * x bf16 [rows][Cx], y f32 [rows][Cy]; `w` is the cg_pack_weights operand for
- * (taps 1, Cx, CK 32).  Supported: Cx in {32, 64, 96, 128}, N <= Cy <= 128,
- * Cy % 4 == 0, epilogue CG_EPI_NONE or CG_EPI_SIGMOID. */
+ * (taps 1, Cx, CK 32).  Epilogue CG_EPI_NONE or CG_EPI_SIGMOID.  Two forms:
+ * Cx in {32, 64, 96, 128} and N <= Cy <= 128 (Cy % 4 == 0): every wave holds W
+ * in registers; otherwise Cx in {128, 256, 384, 512}, any N <= Cy (Cy % 8 == 0):
+ * a workgroup holds one 128-column panel of W in LDS (BASELINE configs[4]:
+ * 512 -> 512). */
 int cg_dense_rows(const void* x, const void* w, const float* bias, float* y,
                   long long rows, int Cx, int N, int Cy, int epilogue,
                   void* stream);
+/* The same contraction with an activation-typed (bf16 / fp16) output, no bias,
+ * no epilogue -- the input gradient of that Dense: dh[r, c] = sum_n dz[r, n] *
+ * W[c][n] with `w` the operand packed from W transposed.  Cx in {128, 256, 384,
+ * 512}, N <= Cy, Cy % 8 == 0; columns [N, Cy) are written as zeros. */
+int cg_dense_rows_act(const void* x, const void* w, void* y, long long rows,
+                      int Cx, int N, int Cy, void* stream);
 /* elements (bf16) of one packed phase operand for (N, taps, Cx, CK) */
 long long cg_packed_elems(int N, int taps, int Cx, int CK);
 

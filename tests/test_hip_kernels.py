@@ -472,6 +472,51 @@ def test_dense_rows_streaming(rows, Ci, Co, epi):
     assert float(got[:, Co:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('rows,Ci,Co,epi', [(1000, 512, 512, 3), (77, 256, 200, 0),
+                                            (4100, 512, 300, 0), (33, 384, 130, 3),
+                                            (9000, 128, 102, 0)])
+def test_dense_rows_wide(rows, Ci, Co, epi):
+  """The LDS-panel form of cg_dense_rows (K or N beyond 128: BASELINE
+  configs[4]'s 512 -> 512 per-timestep Dense) and its activation-typed twin
+  cg_dense_rows_act (the input gradient dh = dz W^T): exact on integer data,
+  f32 tolerance through the sigmoid, padding columns zero, ragged row counts,
+  several 128-column panels, row blocks that wrap the grid."""
+  rng = np.random.RandomState(22)
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  x = H.int_tensor(rng, (1, rows, Ci), -3, 3)
+  W = H.int_tensor(rng, (Ci, Co), -2, 2, 0.25)
+  b = H.int_tensor(rng, (Co,), -2, 2, 0.5)
+  op = H.pack(W.to(H.DEV), [(0, 1, 0, Co, 1)], Ci, Co, cip, 32, 1)
+  xd = H.to_pitch(x, cip)
+  bd = b.to(H.DEV)
+  ref = x[0] @ W
+  if Ci > 128 or Co > 128:  # (else cg_dense_rows takes its register form)
+    cf = (Co + 7) // 8 * 8
+    y = torch.full((rows, cf), 9.0, dtype=torch.float32, device=H.DEV)
+    _lib.call('cg_dense_rows', H.p(xd), H.p(op.buf), H.p(bd), H.p(y), rows, cip,
+              Co, cf, epi, H.stream())
+    H.sync()
+    got = y.cpu()
+    if epi == 3:
+      np.testing.assert_allclose(got[:, :Co].numpy(),
+                                 torch.sigmoid(ref + b).numpy(), rtol=2e-6,
+                                 atol=1e-6)
+    else:
+      np.testing.assert_array_equal(got[:, :Co].numpy(), (ref + b).numpy())
+    if cf > Co:
+      assert float(got[:, Co:].abs().max()) == 0.0
+  # activation-typed output, no bias: every value below is exact in bf16
+  ya = torch.full((rows, cop), 9.0, dtype=BF16, device=H.DEV)
+  _lib.call('cg_dense_rows_act', H.p(xd), H.p(op.buf), H.p(ya), rows, cip, Co,
+            cop, H.stream())
+  H.sync()
+  gota = ya.float().cpu()
+  np.testing.assert_array_equal(gota[:, :Co].numpy(),
+                                ref.to(BF16).float().numpy())
+  if cop > Co:
+    assert float(gota[:, Co:].abs().max()) == 0.0
+
+
 WGRAD_CASES = [
     (3, 128, 102, 64, 24, 1, True),
     (2, 64, 16, 40, 24, 2, False),
