@@ -62,9 +62,11 @@ def algorithmic_flops(hp):
   streaming = geo.dense_streams(cp)
   # ((n + 1) forwards; + the input gradient dh = dz W^T of the generator update,
   # streaming for pitches >= 128)
-  dense_rows = ((n + 1) + (1 if cp >= 128 else 0)) * f_dense if streaming else 0.0
-  swconv = n * (f_g + 7 * f_d - 2 * f_d1) + 2 * f_g + 2 * f_d - dense_rows
-  wgrad = n * 3 * f_d + f_g
+  dense_fwd_bwd = ((n + 1) + (1 if cp >= 128 else 0)) * f_dense if streaming else 0.0
+  # its weight gradient always runs in cg_dense_wgrad (not a cg_wgrad launch)
+  dense_rows = dense_fwd_bwd + f_dense
+  swconv = n * (f_g + 7 * f_d - 2 * f_d1) + 2 * f_g + 2 * f_d - dense_fwd_bwd
+  wgrad = n * 3 * f_d + f_g - f_dense
   total = (n + 3) * f_g + (10 * n + 2) * f_d - 2 * n * f_d1
   assert abs(total - swconv - wgrad - dense_rows) < 1e-3 * total
   return dict(total=total, swconv=swconv, wgrad=wgrad, f_g=f_g, f_d=f_d,

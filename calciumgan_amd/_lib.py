@@ -109,6 +109,9 @@ SIGNATURES = {
     'cg_swconv_check': [C.POINTER(ConvDesc)],
     'cg_dense_rows': [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_vp],
     'cg_dense_rows_act': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],
+    'cg_dense_wgrad': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_vp, c_ll,
+                       c_vp],
+    'cg_dense_wgrad_ws_elems': [c_ll, c_i, c_i],
     'cg_packed_elems': [c_i, c_i, c_i, c_i],
     'cg_pack_weights': [C.POINTER(PackDesc), c_vp],
     'cg_pack_plan_bytes': [c_i, c_ll],
@@ -151,7 +154,8 @@ SIGNATURES = {
                           c_vp],
 }
 _RESTYPES = {'cg_packed_elems': c_ll, 'cg_pack_plan_bytes': c_ll,
-             'cg_pack_plan_build': c_ll, 'cg_wgrad_partials_elems': c_ll}
+             'cg_pack_plan_build': c_ll, 'cg_wgrad_partials_elems': c_ll,
+             'cg_dense_wgrad_ws_elems': c_ll}
 
 _libs = {}       # precision -> ctypes handle
 _active = 'bf16'  # precision of the library `call` / `load()` address

@@ -349,6 +349,158 @@ int dense_rows_wide(const void* x, const void* w, const float* bias, void* y,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradient of the per-timestep Dense: dW[cx][cg] += sum_r x[r][cx] g[r][cg]
+// (rows = B * L: 262 144 at cfg2, 2 M at configs[4]).  The generic cg_wgrad path
+// (taps = 1: eight waves splitting the rows of one 32 x 64 tile, operands read in
+// 64-byte slivers) ran it at 0.09-0.15 PFLOP/s.  Here a workgroup owns a
+// 128 x 128 tile of dW and a contiguous range of rows: 32-row stages of x and g
+// (256-byte row segments) go registers -> LDS (row-major, pitch 288 B = 32 x 9:
+// conflict-free transpose reads) double-buffered against the next stage's
+// global loads; each of the four waves keeps a 64 x 64 block in 64 registers,
+// fragments come from ds_read_b64_tr_b16 (both operands are K'-major).  The
+// workgroups of one row range (all tiles) share an XCD; partial tiles meet in dW
+// through f32 atomics (a few MB per launch).
+constexpr int kDwThreads = 256;
+constexpr int kDwPitch = 144;  // elements: 128 channels + 16 pad
+
+struct DenseWgradArgs {
+  const uint16_t* x;
+  const uint16_t* g;
+  float* dw;
+  long long rows, rows_per_split;
+  int Cx, Cg, Cx_real, Cg_real, tiles_x, tiles_g;
+  float* part;  // [row range][Cx_real][Cg_real] partial sums, or null: atomics
+};
+
+__device__ __forceinline__ s16x4 dw_tr_read(const uint16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ act8 dw_join(s16x4 lo, s16x4 hi) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(act8, v);
+}
+
+__global__ __launch_bounds__(kDwThreads, 2) void dense_wgrad_kernel(
+    DenseWgradArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t lx[2][32 * kDwPitch];
+  __shared__ __attribute__((aligned(16))) uint16_t lg[2][32 * kDwPitch];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r16 = lane & 15, g4 = lane >> 4, q = r16 >> 2, p = r16 & 3;
+  const int wx = wave >> 1, wg = wave & 1;
+  // workgroup -> (tile, split): all tiles of one row range on one XCD
+  const int ntiles = a.tiles_x * a.tiles_g;
+  const int xcd = blockIdx.x & 7;
+  const int j = blockIdx.x >> 3;
+  const int tile = j % ntiles;
+  const long long split = (long long)(j / ntiles) * 8 + xcd;
+  const int cx0 = (tile % a.tiles_x) * 128;
+  const int cg0 = (tile / a.tiles_x) * 128;
+  const long long r_begin = split * a.rows_per_split;
+  long long r_end = r_begin + a.rows_per_split;
+  if (r_end > a.rows) r_end = a.rows;
+  // (an empty row range still stores its zeros in the partial-sum form)
+  if (r_begin >= r_end && !a.part) return;
+
+  // staging map: 512 16-byte pieces per operand and stage, two per thread
+  const int srow = tid >> 4;          // + 16 for the second piece
+  const int sc = (tid & 15) * 8;      // channel of the piece inside the tile
+  const bool okx = cx0 + sc < a.Cx, okg = cg0 + sc < a.Cg;
+  // (four named registers and unconditional loads from clamped addresses: as
+  // arrays behind predicates they were demoted to scratch)
+  uint4 px0, px1, pg0, pg1;
+  const int scx = okx ? cx0 + sc : 0, scg = okg ? cg0 + sc : 0;
+  auto fetch1 = [&](long long row, uint4& vx, uint4& vg) {
+    const bool ok = row < r_end;
+    const long long rc = ok ? row : r_end - 1;
+    vx = *reinterpret_cast<const uint4*>(a.x + rc * a.Cx + scx);
+    vg = *reinterpret_cast<const uint4*>(a.g + rc * a.Cg + scg);
+    if (!(ok && okx)) vx = make_uint4(0u, 0u, 0u, 0u);
+    if (!(ok && okg)) vg = make_uint4(0u, 0u, 0u, 0u);
+  };
+  auto fetch = [&](long long r0) {
+    fetch1(r0 + srow, px0, pg0);
+    fetch1(r0 + srow + 16, px1, pg1);
+  };
+  auto stash = [&](int buf) {
+    *reinterpret_cast<uint4*>(&lx[buf][srow * kDwPitch + sc]) = px0;
+    *reinterpret_cast<uint4*>(&lg[buf][srow * kDwPitch + sc]) = pg0;
+    *reinterpret_cast<uint4*>(&lx[buf][(srow + 16) * kDwPitch + sc]) = px1;
+    *reinterpret_cast<uint4*>(&lg[buf][(srow + 16) * kDwPitch + sc]) = pg1;
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  fetch(r_begin);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (long long r0 = r_begin; r0 < r_end; r0 += 32) {
+    const bool more = r0 + 32 < r_end;
+    if (more) fetch(r0 + 32);  // in flight during this stage's MFMAs
+    const uint16_t* bx = &lx[buf][(4 * g4 + q) * kDwPitch + wx * 64 + 4 * p];
+    const uint16_t* bg = &lg[buf][(4 * g4 + q) * kDwPitch + wg * 64 + 4 * p];
+    act8 bf[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      bf[nt] = dw_join(dw_tr_read(bg + nt * 16), dw_tr_read(bg + 16 * kDwPitch + nt * 16));
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const act8 af =
+          dw_join(dw_tr_read(bx + mt * 16), dw_tr_read(bx + 16 * kDwPitch + mt * 16));
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[mt][nt] = cg_mfma_16x16x32(af, bf[nt], acc[mt][nt], 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // accumulator (mt, nt, r): cx = 4 g4 + r, cg = r16 of the 16 x 16 block
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cx = cx0 + wx * 64 + mt * 16 + 4 * g4 + r;
+        const int cg = cg0 + wg * 64 + nt * 16 + r16;
+        if (cx < a.Cx_real && cg < a.Cg_real) {
+          const long long e = (long long)cx * a.Cg_real + cg;
+          if (a.part)
+            a.part[split * ((long long)a.Cx_real * a.Cg_real) + e] = acc[mt][nt][r];
+          else
+            atomicAdd(a.dw + e, acc[mt][nt][r]);
+        }
+      }
+}
+
+// dW[e] += sum over the row ranges of their partial tiles (few output tiles:
+// a thousand workgroups adding into the same 10 K addresses serialise -- 150 us
+// of atomics at cfg2 against 30 us of streaming)
+__global__ void dense_wgrad_reduce_kernel(const float* __restrict__ part,
+                                          float* __restrict__ dw, long long n,
+                                          int nsplit) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // blockIdx.y sums its share of the row ranges (a lone thread walking all of
+  // them is 512 dependent-latency loads: 100 us), one atomic per share
+  const int per = (nsplit + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int k0 = (int)blockIdx.y * per;
+  const int k1 = k0 + per < nsplit ? k0 + per : nsplit;
+  float s = 0.f;
+#pragma unroll 8
+  for (int k = k0; k < k1; ++k) s += part[(long long)k * n + i];
+  if (k1 > k0) atomicAdd(dw + i, s);
+}
+
 }  // namespace
 
 extern "C" int cg_dense_rows(const void* x, const void* w, const float* bias,
@@ -392,4 +544,70 @@ extern "C" int cg_dense_rows_act(const void* x, const void* w, void* y,
   if (!x || !w || !y || rows < 1) return CG_EINVAL;
   return dense_rows_wide(x, w, nullptr, y, rows, Cx, N, Cy, CG_EPI_NONE, 1,
                          (hipStream_t)stream);
+}
+
+// dW[cx][cg] += sum_r x[r][cx] * g[r][cg]  (f32 [Cx_real][Cg_real], row-major;
+// the caller zeroes dW): the weight gradient of the per-timestep Dense.
+extern "C" long long cg_dense_wgrad_ws_elems(long long rows, int Cx_real,
+                                             int Cg_real);
+
+namespace {
+// row ranges of a launch: ~512 workgroups for up to four output tiles (the
+// partial-sum form), ~1 024 beyond; whole 32-row stages; a multiple of 8 ranges
+// (the XCD residue is part of the range id)
+void dense_wgrad_split(long long rows, int ntiles, long long& nsplit,
+                       long long& rps) {
+  nsplit = (ntiles <= 4 ? 512 : 1024) / ntiles / 8 * 8;
+  if (nsplit < 8) nsplit = 8;
+  rps = (rows + nsplit - 1) / nsplit;
+  rps = (rps + 31) / 32 * 32;
+  nsplit = ((rows + rps - 1) / rps + 7) / 8 * 8;
+}
+}  // namespace
+
+extern "C" long long cg_dense_wgrad_ws_elems(long long rows, int Cx_real,
+                                             int Cg_real) {
+  if (rows < 1 || Cx_real < 1 || Cg_real < 1) return -1;
+  const int ntiles = ((Cx_real + 127) / 128) * ((Cg_real + 127) / 128);
+  if (ntiles > 4) return 0;  // many tiles: atomics, no workspace
+  long long nsplit, rps;
+  dense_wgrad_split(rows, ntiles, nsplit, rps);
+  return nsplit * (long long)Cx_real * Cg_real;
+}
+
+// dW[cx][cg] += sum_r x[r][cx] * g[r][cg]  (f32 [Cx_real][Cg_real], row-major;
+// the caller zeroes dW): the weight gradient of the per-timestep Dense.  `ws`
+// (cg_dense_wgrad_ws_elems floats, or null): partial tiles + a reducing launch
+// instead of atomics.
+extern "C" int cg_dense_wgrad(const void* x, const void* g, float* dw,
+                              long long rows, int Cx, int Cg, int Cx_real,
+                              int Cg_real, float* ws, long long ws_elems,
+                              void* stream) {
+  if (!x || !g || !dw || rows < 1) return CG_EINVAL;
+  if (Cx % 8 || Cg % 8 || Cx_real < 1 || Cg_real < 1 || Cx_real > Cx ||
+      Cg_real > Cg)
+    return CG_EINVAL;
+  DenseWgradArgs a;
+  a.x = reinterpret_cast<const uint16_t*>(x);
+  a.g = reinterpret_cast<const uint16_t*>(g);
+  a.dw = dw;
+  a.rows = rows;
+  a.Cx = Cx; a.Cg = Cg; a.Cx_real = Cx_real; a.Cg_real = Cg_real;
+  a.tiles_x = (Cx_real + 127) / 128;
+  a.tiles_g = (Cg_real + 127) / 128;
+  const int ntiles = a.tiles_x * a.tiles_g;
+  if (ntiles > 256) return CG_EINVAL;
+  long long nsplit, rps;
+  dense_wgrad_split(rows, ntiles, nsplit, rps);
+  a.rows_per_split = rps;
+  const long long n = (long long)Cx_real * Cg_real;
+  a.part = (ws && ntiles <= 4 && ws_elems >= nsplit * n) ? ws : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(dense_wgrad_kernel, dim3((unsigned)(nsplit * ntiles)),
+                     dim3(kDwThreads), 0, s, a);
+  if (a.part)
+    hipLaunchKernelGGL(dense_wgrad_reduce_kernel,
+                       dim3((unsigned)((n + 255) / 256), 32), dim3(256), 0, s,
+                       a.part, dw, n, (int)nsplit);
+  CG_LAUNCH_CHECK();
 }

@@ -1013,9 +1013,10 @@ class _GenWorkspace(object):
     self.b_out_dgrad = None if net.streaming_out_dgrad else _conv_desc(
         self.dz, net.w_out_t.buf, self.dh[-1], B, net.L, net.Cp, 1, 1, 0, net.L,
         net.C, net.L, net.Cp, net.w_out_t.CK)
-    self.b_out_wgrad = _wgrad_desc(self.h[-1], self.dz, G[net.idx_out], B,
-                                   net.L, net.Cp, net.L, net.Cp, 1, 1, 0, net.C,
-                                   net.C)
+    # (partial tiles of the output Dense's weight gradient: cg_dense_wgrad)
+    need = _lib.load().cg_dense_wgrad_ws_elems(B * net.L, net.C, net.C)
+    self.out_wgrad_ws = (torch.empty(need, dtype=torch.float32, device=dev)
+                         if need > 0 else None)
     self.b_dgrad, self.b_wgrad = [], []
     for i, (lay, ic) in enumerate(zip(net.layers, net.idx_conv)):
       op = net.w_dgrad[i]
@@ -1073,7 +1074,11 @@ class _GenWorkspace(object):
                 rows, net.C, net.Cf, net.Cp, st)
     else:
       self.dz.copy_(dfake.view_as(self.dz))  # linear output: dz = dfake
-    _run_wgrad(self.b_out_wgrad, st)
+    # dW of the per-timestep Dense: the streaming kernel (the generic cg_wgrad
+    # path, taps = 1, reads its operands in 64-byte slivers: 92 -> 31 us at cfg2)
+    _lib.call('cg_dense_wgrad', _p(self.h[-1]), _p(self.dz), _p(G[net.idx_out]),
+              rows, net.Cp, net.Cp, net.C, net.C, _p(self.out_wgrad_ws),
+              0 if self.out_wgrad_ws is None else self.out_wgrad_ws.numel(), st)
     _lib.call('cg_colsum', _p(self.dz), _p(G[net.idx_out + 1]), rows, net.C,
               net.Cp, st)
     if net.streaming_out_dgrad:

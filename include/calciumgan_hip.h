@@ -203,6 +203,18 @@ int cg_dense_rows(const void* x, const void* w, const float* bias, float* y,
  * 512}, N <= Cy, Cy % 8 == 0; columns [N, Cy) are written as zeros. */
 int cg_dense_rows_act(const void* x, const void* w, void* y, long long rows,
                       int Cx, int N, int Cy, void* stream);
+/* Weight gradient of that Dense: dW[cx][cg] += sum_r x[r][cx] * g[r][cg], dW f32
+ * [Cx_real][Cg_real] row-major (the Keras kernel layout; the caller zeroes it),
+ * x [rows][Cx], g [rows][Cg] bf16 / fp16, pitches multiples of 8.  Streaming
+ * form: 128 x 128 tiles of dW x row ranges, K'-major operands through LDS
+ * transpose reads.  The row ranges' partial tiles meet through f32 atomics, or
+ * -- with a workspace of cg_dense_wgrad_ws_elems(...) floats (> 0 when dW has
+ * at most four tiles, where a thousand workgroups' atomics on the same
+ * addresses would serialise) -- through plain stores and a reducing launch. */
+long long cg_dense_wgrad_ws_elems(long long rows, int Cx_real, int Cg_real);
+int cg_dense_wgrad(const void* x, const void* g, float* dw, long long rows,
+                   int Cx, int Cg, int Cx_real, int Cg_real, float* ws,
+                   long long ws_elems, void* stream);
 /* elements (bf16) of one packed phase operand for (N, taps, Cx, CK) */
 long long cg_packed_elems(int N, int taps, int Cx, int CK);
 

@@ -517,6 +517,30 @@ def test_dense_rows_wide(rows, Ci, Co, epi):
     assert float(gota[:, Co:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('rows,Ci,Co', [(4096, 102, 102), (70, 32, 256),
+                                        (33000, 512, 512), (1000, 130, 40)])
+def test_dense_wgrad_streaming(rows, Ci, Co):
+  """cg_dense_wgrad: dW += x^T g for the per-timestep Dense, exact on integer
+  data whatever the number of 128 x 128 tiles and row ranges (partial tiles
+  meet through f32 atomics: integer sums are order-independent); ragged row
+  count; accumulates into dW."""
+  rng = np.random.RandomState(23)
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  x = H.int_tensor(rng, (1, rows, Ci), -2, 2)
+  g = H.int_tensor(rng, (1, rows, Co), -2, 2)
+  xd, gd = H.to_pitch(x, cip), H.to_pitch(g, cop)
+  ref = x[0].double().t() @ g[0].double() + 3.0
+  need = _lib.load().cg_dense_wgrad_ws_elems(rows, Ci, Co)
+  assert (need > 0) == (((Ci + 127) // 128) * ((Co + 127) // 128) <= 4)
+  ws = torch.full((max(need, 1),), float('nan'), device=H.DEV)
+  for use_ws in ([False, True] if need > 0 else [False]):
+    dw = torch.full((Ci, Co), 3.0, dtype=torch.float32, device=H.DEV)
+    _lib.call('cg_dense_wgrad', H.p(xd), H.p(gd), H.p(dw), rows, cip, cop, Ci,
+              Co, H.p(ws) if use_ws else None, need if use_ws else 0, H.stream())
+    H.sync()
+    np.testing.assert_array_equal(dw.cpu().double().numpy(), ref.numpy())
+
+
 WGRAD_CASES = [
     (3, 128, 102, 64, 24, 1, True),
     (2, 64, 16, 40, 24, 2, False),

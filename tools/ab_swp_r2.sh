@@ -1,6 +1,6 @@
 set -u
 o=gpurun_out/ab1; mkdir -p $o
-R2=$PWD/calciumgan_amd/csrc/libcalciumgan_hip_r2swp.so
+R2=${R2:-$PWD/calciumgan_amd/csrc/libcalciumgan_hip_r2swp.so}  # build: git show <old>:calciumgan_amd/csrc/swconv_swp.hip, hipcc -c, link with the current objects
 for rep in 1 2; do
   cp profiles/r02_tuned_tiles.json $o/tA.json; cp profiles/r02_tuned_tiles.json $o/tB.json
   CALCIUMGAN_TILE_CACHE=$o/tA.json CALCIUMGAN_HIP_LIB=$R2 python bench.py --no_cpu_baseline --steps 40 > $o/benchA_$rep.log 2>&1

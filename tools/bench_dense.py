@@ -50,3 +50,11 @@ if Cx >= 128:
   print('dense_rows_act rows %d Cx %d N %d: %.1f us  %.1f TF/s  %.2f TB/s' % (
       rows, Cx, N, t * 1e6, fl / t / 1e12,
       rows * (Cx * 2 + geo.pitch(N) * 2) / t / 1e12))
+g = torch.randn(rows, geo.pitch(N), device='cuda').to(dt)
+dw = torch.zeros(Cx, N, device='cuda')
+need = _lib.load().cg_dense_wgrad_ws_elems(rows, Cx, N)
+ws = torch.empty(max(need, 1), device='cuda')
+t = timeit(lambda: _lib.call('cg_dense_wgrad', nets._p(x), nets._p(g), nets._p(dw), rows,
+                             Cx, geo.pitch(N), Cx, N, nets._p(ws), need, st))
+print('dense_wgrad    rows %d Cx %d N %d: %.1f us  %.1f TF/s  %.2f TB/s' % (
+    rows, Cx, N, t * 1e6, fl / t / 1e12, rows * (Cx * 2 + geo.pitch(N) * 2) / t / 1e12))
