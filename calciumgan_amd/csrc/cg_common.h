@@ -92,11 +92,40 @@ __device__ __forceinline__ int shuffle_src(int t, int s, int w) {
   return t < a ? a - t : t - a;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane sums without the LDS crossbar: __shfl_xor compiles to
+// ds_bpermute_b32 (an LDS-pipe round trip of ~100 cycles per step, six dependent
+// steps per wave sum -- the LayerNorm kernels spent most of their time there);
+// DPP moves inside a 16-lane row cost one VALU op each and gfx950's
+// v_permlane16_swap / v_permlane32_swap pair the rows.  After step k every lane
+// holds the sum of its 2^k-lane group, so any pairing of the groups will do
+// (quad swaps, half-row / row mirrors, row swaps).
+template <int CTRL>
+__device__ __forceinline__ float dpp_partner(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(
+      0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum_partner(float v) {
+  const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v),
+                                                   __float_as_uint(v), false, false);
+  return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+__device__ __forceinline__ float half32_sum_partner(float v) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v),
+                                                   __float_as_uint(v), false, false);
+  return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+// sum over aligned groups of `n` lanes (n a power of two, 1 .. 64); every lane
+// of a group receives the group's sum
+__device__ __forceinline__ float group_sum_n(float v, int n) {
+  if (n > 1) v += dpp_partner<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (n > 2) v += dpp_partner<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (n > 4) v += dpp_partner<0x141>(v);   // row_half_mirror
+  if (n > 8) v += dpp_partner<0x140>(v);   // row_mirror
+  if (n > 16) v = row16_sum_partner(v);    // rows 0+1, 2+3
+  if (n > 32) v = half32_sum_partner(v);   // halves
   return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return group_sum_n(v, 64); }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -66,8 +66,7 @@ __device__ __forceinline__ void load8f(const float* p, int nvalid, int pitch,
 // LPR-lane group.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float group_sum(float v, int lpr) {
-  for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return group_sum_n(v, lpr);  // DPP / permlane swaps, no LDS round trips
 }
 
 __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(
