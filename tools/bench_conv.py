@@ -54,8 +54,14 @@ def main():
       CK = nets._ck_for(Cx, R, taps, Lu)
     x = torch.randn(nB, Lx, Cx, device=dev).to(BF16)
     W = torch.randn(taps, Cx, N, device=dev)
-    op = nets.PackedOperand(W, [(0, 1, Cx * N, N, 1)] * nphase, Cx, N, Cx, CK,
-                            taps, parity_major=R == 2)
+    # BENCH_CREAL=<real channels> (< Cx): zero-padded source channels, e.g. 102
+    # in a 128 pitch -- the narrow-last-chunk operand of the critic's first layer
+    creal = int(os.environ.get('BENCH_CREAL', Cx))
+    if creal < Cx:
+      x[:, :, creal:] = 0
+      W = W[:, :creal].contiguous()
+    op = nets.PackedOperand(W, [(0, 1, creal * N, N, 1)] * nphase, creal, N, Cx,
+                            CK, taps, parity_major=R == 2)
     op.repack()
     y = torch.zeros(nB, Ly, Cy, device=dev,
                     dtype=torch.float32 if f32 else BF16)
@@ -66,7 +72,7 @@ def main():
                         mask_src=y if epi == 2 else None, out_f32=bool(f32),
                         nphase=nphase, w_phase_stride=op.elems,
                         off_phase_step=1, yoff_phase_step=1, rowsumsq=ssq,
-                        w_parity_major=R == 2)
+                        w_parity_major=R == 2, w_narrow_last=op.narrow_last)
     if small >= 0:
       d.tile = small
       d.stage_ksteps = ksteps
