@@ -12,7 +12,8 @@ print("total kernel ms/step %.2f" % (tot / 1e6 / steps))
 # (swconv_swp_kernel) and the split-K finishing launches ride in one family, as
 # bench.py times them; wgrad: wgrad_kernel + wgrad_multi_kernel + the reduce
 for fam, pats in (("swconv", ("swconv_kernel", "swconv_swp_kernel")),
-                  ("wgrad", ("wgrad",))):
+                  # (cg_wgrad's kernels; not dense_wgrad_kernel / dense1_wgrad_kernel)
+                  ("wgrad", ("::wgrad_",))):
     sel = [r for r in rows if any(p in r["Name"] for p in pats)]
     calls = sum(int(r["Calls"]) for r in sel)
     ns = sum(float(r["TotalDurationNs"]) for r in sel)
