@@ -46,3 +46,73 @@ def correlation_coefficients(spikes1, spikes2=None, binsize_ms=500.0):
   if spikes2 is not None:
     r = r[len(spikes1):, :len(spikes2)]
   return r
+
+
+def spike_times(spikes):
+  """spike_helper.py:8-20 (train_to_neo / trains_to_neo without Neo): per train
+  the spike times in seconds (frame / 24 Hz); t_stop = T / 24 s."""
+  spikes = np.asarray(spikes)
+  assert spikes.ndim == 2
+  return [np.nonzero(tr)[0] / float(FRAME_RATE) for tr in spikes]
+
+
+def _exp_sum(a, b, tau):
+  """sum_k sum_l exp(-|a_k - b_l| / tau)."""
+  if len(a) == 0 or len(b) == 0:
+    return 0.0
+  return float(np.exp(-np.abs(a[:, None] - b[None, :]) / tau).sum())
+
+
+def van_rossum_distance(spikes1, spikes2=None, tau=1.0):
+  """spike_metrics.py:41-51 -> elephant.spike_train_dissimilarity.van_rossum_dist
+  (tau = 1 s default [ext]): each train is convolved with exp(-t / tau) H(t) and
+  D[i, j]^2 = (1 / tau) int (f_i - f_j)^2 dt = 1/2 (S_ii + S_jj - 2 S_ij),
+  S_ab = sum_k sum_l exp(-|t_k - t_l| / tau)  (Houghton & Kreuz 2012: the closed
+  form Elephant evaluates; a single spike against an empty train is sqrt(1/2)).
+  Returns the full matrix, or the (spikes2 x spikes1) cross block exactly as
+  the reference slices it (result[len(spikes1):, :len(spikes2)]).  PARITY
+  UNPINNED (Elephant absent); the KL statistics compute_metrics.py builds on
+  it do not depend on the normalisation."""
+  spikes = np.asarray(spikes1) if spikes2 is None else np.concatenate(
+      [np.asarray(spikes1), np.asarray(spikes2)], 0)
+  # S = A E A^T: E the kernel between ALL spikes of the batch, A the train
+  # membership (one matrix product instead of n^2 python-level pair sums: a
+  # 102-neuron trial is 5 000 pairs)
+  owner, frame = np.nonzero(spikes)
+  n = len(spikes)
+  t = frame / float(FRAME_RATE)
+  E = np.exp(-np.abs(t[:, None] - t[None, :]) / tau)
+  A = np.zeros((n, len(t)), np.float64)
+  A[owner, np.arange(len(t))] = 1.0
+  S = A @ E @ A.T
+  d2 = 0.5 * (np.diag(S)[:, None] + np.diag(S)[None, :] - 2.0 * S)
+  result = np.sqrt(np.maximum(d2, 0.0))
+  if spikes2 is not None:
+    result = result[len(spikes1):, :len(spikes2)]
+  return result
+
+
+def victor_purpura_distance(spikes1, spikes2=None, q=1.0):
+  """spike_metrics.py:54-63 -> elephant victor_purpura_dist (q = 1 Hz default
+  [ext]): minimal cost of turning one train into the other with insert / delete
+  (cost 1) and shifts (cost q |dt|); dynamic programme of Victor & Purpura 1996.
+  PARITY UNPINNED."""
+  spikes = np.asarray(spikes1) if spikes2 is None else np.concatenate(
+      [np.asarray(spikes1), np.asarray(spikes2)], 0)
+  times = spike_times(spikes)
+  n = len(times)
+  result = np.zeros((n, n), np.float64)
+  for i in range(n):
+    for j in range(i + 1, n):
+      a, b = times[i], times[j]
+      G = np.zeros((len(a) + 1, len(b) + 1))
+      G[:, 0] = np.arange(len(a) + 1)
+      G[0, :] = np.arange(len(b) + 1)
+      for k in range(1, len(a) + 1):
+        for l in range(1, len(b) + 1):
+          G[k, l] = min(G[k - 1, l] + 1, G[k, l - 1] + 1,
+                        G[k - 1, l - 1] + q * abs(a[k - 1] - b[l - 1]))
+      result[i, j] = result[j, i] = G[-1, -1]
+  if spikes2 is not None:
+    result = result[len(spikes1):, :len(spikes2)]
+  return result

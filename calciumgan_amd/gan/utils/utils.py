@@ -147,3 +147,25 @@ def generate_dataset(hparams, gan, num_samples=1000):
     pickle.dump({'signals': generated}, file)
   if hparams.verbose:
     print('save {} samples to {}'.format(num_samples, filename))
+
+
+def get_array_format(shape, hparams):
+  """utils.py:155-165: 'N' samples / 'W' sequence length / 'C' channels."""
+  assert len(shape) <= 3
+  return ''.join('W' if s == hparams.sequence_length else
+                 'C' if s == hparams.num_neurons else 'N' for s in shape)
+
+
+def set_array_format(array, data_format, hparams):
+  """utils.py:168-184."""
+  assert len(array.shape) == len(data_format)
+  current_format = get_array_format(array.shape, hparams)
+  assert set(current_format) == set(data_format)
+  if data_format == current_format:
+    return array
+  return np.transpose(array, axes=[current_format.index(s) for s in data_format])
+
+
+def remove_nan(array):
+  """utils.py:187-188."""
+  return array[np.logical_not(np.isnan(array))]

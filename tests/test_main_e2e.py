@@ -114,3 +114,37 @@ def test_main_mixed_precision_runs_fp16_with_loss_scaling(tmp_path):
   # applied steps: at most 8 train() x (5 + 1) updates, fewer if the scaler
   # had to skip overflowing ones on its way down from 2**15
   assert 0 < int(ck['dis_steps']) <= 40 and 0 < int(ck['gen_steps']) <= 8
+
+
+def test_recorded_data_pipeline_tfrecords_to_spike_metrics(tmp_path):
+  """BASELINE configs[3]'s pipeline end to end (no recorded data exists here:
+  DG calcium written in the reference's TFRecord layout stands in for it):
+  train-*/validation-*.record shards of tf.train.Example{signal, spike}
+  (dataset/generate_tfrecords.py, read by gan/utils/tfrecord.py without
+  TensorFlow) -> main.py -> generated/epochNNN_signals.h5 + validation.h5 ->
+  compute_metrics.py: OASIS deconvolution written back into the generated file,
+  KL of firing rate / correlation / van Rossum distance, recorded vs synthetic."""
+  import compute_metrics as cm
+  d = dg.make_dataset(num_neurons=16, sequence_length=256, num_segments=70)
+  info = {k: v for k, v in d['info'].items() if k != 'rates_hz'}
+  ds = str(tmp_path / 'ds_tfr')
+  dataset_helper.write_dataset(ds, d['signals'], d['spikes'], info,
+                               validation_size=6, tfrecords=True, num_per_shard=40)
+  assert len(glob.glob(os.path.join(ds, 'train-*.record'))) == 2
+  out = str(tmp_path / 'run_tfr')
+  hp = _args(ds, out, '--epochs', '2')
+  cli.main(hp)
+  gen_file = os.path.join(out, 'generated', 'epoch001_signals.h5')
+  assert h5_helper.get(gen_file, 'signals').shape == (6, 256, 16)
+  mhp = cm.build_parser().parse_args(['--output_dir', out, '--num_processors',
+                                      '1', '--verbose', '0'])
+  rep = cm.main(mhp)
+  assert list(rep) == [1]                       # the last generated epoch
+  r = rep[1]
+  spikes = h5_helper.get(gen_file, 'spikes')
+  assert spikes.shape == (6, 256, 16) and set(np.unique(spikes)) <= {0, 1}
+  for k in ('firing_rate_kl', 'correlation_kl', 'van_rossum_kl'):
+    assert np.isfinite(r[k]['mean']) and r[k]['mean'] >= 0, (k, r[k])
+  assert len(r['firing_rate_kl']['neurons']) == 6
+  saved = json.load(open(os.path.join(out, 'spike_metrics.json')))
+  assert saved['1']['van_rossum_kl']['mean'] == r['van_rossum_kl']['mean']

@@ -145,3 +145,92 @@ def test_oasis_solves_its_defining_problem():
     np.testing.assert_allclose(c_hat, c_ref, atol=1e-8)
     # (s[0] is defined as 0 by the reference's convention; the rest agree)
     np.testing.assert_allclose(s_hat[1:], s_ref[1:], atol=1e-8)
+
+
+def test_van_rossum_and_victor_purpura_known_answers():
+  """Closed forms of the two spike-train distances (spike_metrics.py:41-63 ->
+  Elephant [ext], tau = 1 s, q = 1 Hz): a lone spike against an empty train is
+  sqrt(1/2); two lone spikes dt apart sqrt(1 - exp(-dt)); identical trains 0;
+  Victor-Purpura moves a spike for q dt or deletes + inserts it for 2."""
+  T = 24 * 20
+  a, b, c, e = (np.zeros(T, np.float32) for _ in range(4))
+  a[24] = 1            # spike at 1 s
+  b[24 + 12] = 1       # spike at 1.5 s
+  c[[24, 24 * 10]] = 1 # spikes at 1 s and 10 s
+  d = spike_metrics.van_rossum_distance(np.stack([a, b, c, e]))
+  assert d.shape == (4, 4) and np.allclose(np.diag(d), 0)
+  np.testing.assert_allclose(d[0, 3], np.sqrt(0.5), rtol=1e-12)
+  np.testing.assert_allclose(d[0, 1], np.sqrt(1 - np.exp(-0.5)), rtol=1e-12)
+  # a's spike cancels c's first one: what is left is c's lone second spike
+  np.testing.assert_allclose(d[0, 2], np.sqrt(0.5), rtol=1e-12)
+  np.testing.assert_allclose(d, d.T)
+  # the cross block is sliced as the reference slices it
+  cross = spike_metrics.van_rossum_distance(np.stack([a, b]), np.stack([c, e]))
+  np.testing.assert_allclose(cross, d[2:, :2])
+  vp = spike_metrics.victor_purpura_distance(np.stack([a, b, c, e]))
+  np.testing.assert_allclose(vp[0, 1], 0.5)      # shift by 0.5 s at q = 1
+  np.testing.assert_allclose(vp[0, 3], 1.0)      # delete
+  np.testing.assert_allclose(vp[0, 2], 1.0)      # insert the second spike
+  far = np.zeros(T, np.float32)
+  far[24 * 15] = 1
+  np.testing.assert_allclose(
+      spike_metrics.victor_purpura_distance(np.stack([a, far]))[0, 1], 2.0)
+
+
+def test_recorded_data_metrics_report(tmp_path):
+  """compute_metrics.py (BASELINE configs[3]'s post-hoc chain) on a run
+  directory: deconvolution written back into the generated file, KL of firing
+  rate / correlation / van Rossum distances between validation and generated
+  spikes.  Generated == the validation calcium: the firing-rate histograms
+  differ only by what OASIS misses, correlation and van Rossum KLs stay small;
+  a shuffled generated set scores worse; identical spike sets score exactly 0."""
+  import compute_metrics as cm
+  import json
+  d = dg.make_dataset(num_neurons=6, sequence_length=480, num_segments=24)
+  gen_dir = tmp_path / 'generated'
+  os.makedirs(gen_dir)
+  val = str(gen_dir / 'validation.h5')
+  sig = d['signals'] * (d['info']['signals_max'] - d['info']['signals_min']
+                        ) + d['info']['signals_min']
+  h5_helper.write(val, {'signals': sig.astype(np.float32),
+                        'spikes': d['spikes'].astype(np.int8)})
+  fake = str(gen_dir / 'epoch000_signals.h5')
+  h5_helper.write(fake, {'signals': sig.astype(np.float32)})
+  with open(gen_dir / 'info.pkl', 'wb') as f:
+    pickle.dump({0: {'global_step': 1, 'filename': fake}}, f)
+  json.dump(dict(generated_dir=str(gen_dir), validation_cache=val,
+                 num_neurons=6, sequence_length=480),
+            open(tmp_path / 'hparams.json', 'w'))
+  hp = cm.build_parser().parse_args(['--output_dir', str(tmp_path),
+                                     '--num_processors', '1', '--verbose', '0'])
+  r = cm.main(hp)[0]
+  assert h5_helper.contains(fake, 'spikes')
+  got = h5_helper.get(fake, 'spikes')
+  assert got.shape == d['spikes'].shape and got.dtype == np.int8
+  assert set(r) >= {'firing_rate_kl', 'correlation_kl', 'van_rossum_kl'}
+  assert np.isfinite([r['firing_rate_kl']['mean'], r['correlation_kl']['mean'],
+                      r['van_rossum_kl']['mean']]).all()
+  assert os.path.exists(tmp_path / 'spike_metrics.json')
+  # identical spike sets: every KL is exactly zero
+  h5_helper.overwrite(fake, 'spikes', d['spikes'].astype(np.int8))
+  z = cm.main(hp)[0]
+  assert z['firing_rate_kl']['mean'] == 0 and z['van_rossum_kl']['mean'] == 0
+  assert z['correlation_kl']['mean'] == 0
+  # neurons permuted in the generated set: per-neuron firing rates no longer match
+  h5_helper.overwrite(fake, 'spikes',
+                      d['spikes'][:, :, ::-1].astype(np.int8).copy())
+  w = cm.main(hp)[0]
+  assert w['firing_rate_kl']['mean'] > z['firing_rate_kl']['mean']
+  # KL helper against a direct numpy evaluation
+  rng = np.random.RandomState(0)
+  a, b = rng.randn(300), rng.randn(200) + 0.5
+  pooled = np.concatenate([a, b])
+  lo, hi = pooled.min(), pooled.max()
+  edges = np.linspace(lo, hi, cm.NUM_BINS + 1)
+  edges[0] -= (hi - lo) * 1e-3   # pandas.cut widens the range by 0.1 % below
+  idx = np.clip(np.searchsorted(edges, pooled, side='left') - 1, 0, cm.NUM_BINS - 1)
+  p = np.bincount(idx[:300], minlength=cm.NUM_BINS) / 300.0
+  q = np.bincount(idx[300:], minlength=cm.NUM_BINS) / 200.0
+  np.testing.assert_allclose(cm.pairs_kl_divergence([(a, b)])[0],
+                             cm.kl_divergence(p.astype(np.float32),
+                                              q.astype(np.float32)), rtol=1e-5)
