@@ -145,6 +145,7 @@ def test_recorded_data_pipeline_tfrecords_to_spike_metrics(tmp_path):
   assert spikes.shape == (6, 256, 16) and set(np.unique(spikes)) <= {0, 1}
   for k in ('firing_rate_kl', 'correlation_kl', 'van_rossum_kl'):
     assert np.isfinite(r[k]['mean']) and r[k]['mean'] >= 0, (k, r[k])
-  assert len(r['firing_rate_kl']['neurons']) == 6
+  # (the reference draws its plot neurons WITH replacement: np.random.choice)
+  assert 1 <= len(r['firing_rate_kl']['neurons']) <= 6
   saved = json.load(open(os.path.join(out, 'spike_metrics.json')))
   assert saved['1']['van_rossum_kl']['mean'] == r['van_rossum_kl']['mean']
