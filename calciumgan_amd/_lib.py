@@ -63,6 +63,7 @@ class ConvDesc(C.Structure):
       ('out_shifts', c_vp), ('out_seg_size', c_i), ('side', c_vp),
       ('side_rows', c_i),
       ('ksplit', c_i), ('split_ws', c_vp), ('split_ws_elems', c_ll),
+      ('row_scale', c_vp),
   ]
 
 

@@ -1186,6 +1186,12 @@ static int swconv_run(const cg_conv_desc* d, void* stream) {
   }
   a.out_shifts = d->out_shifts; a.out_seg = d->out_seg_size;
   a.side = reinterpret_cast<uint16_t*>(d->side); a.side_rows = d->side_rows;
+  a.row_scale = d->row_scale;
+  // (software-pipelined tiles only; the split-K finishing launch and the fused
+  // LayerNorm do not carry it)
+  if (d->row_scale && (!tc.swp_wm || a.ksplit > 1 ||
+                       d->epilogue == CG_EPI_LN_LRELU))
+    return CG_EINVAL;
   a.w_phase_stride = d->w_phase_stride;
   a.off_phase_step = d->off_phase_step;
   a.yoff_phase_step = d->yoff_phase_step;

@@ -41,6 +41,7 @@ struct ConvArgs {
   int out_seg;
   uint16_t* side;
   int side_rows;
+  const float* row_scale;  // per-sample scale in front of the epilogue, or null
 };
 
 // swconv_swp.hip: launch (or, dry, only validate) a software-pipelined tile of

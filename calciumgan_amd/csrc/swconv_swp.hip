@@ -612,6 +612,9 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       const int uw0 = mw0 - bw * a.Lu;
       int oshift = 0;
       if (a.out_shifts && bw < a.nB) oshift = a.out_shifts[bw / a.out_seg];
+      // per-sample scale in front of the epilogue (wave-uniform: a scalar load)
+      float rs = 1.f;
+      if (a.row_scale && bw < a.nB) rs = a.row_scale[bw];
       // output row of tile row r of this wave: element offset of its first
       // column; to_side: a reflected row of the output-side PhaseShuffle adjoint
       auto row_target = [&](int r, bool& to_side) {
@@ -661,7 +664,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
           const int n = nl0 + p * 32;
           if (row_ok && n < a.Cy) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bv[p][e];
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[p][e]) * rs;
             if (a.epilogue == CG_EPI_LRELU) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], a.alpha * v[e]);

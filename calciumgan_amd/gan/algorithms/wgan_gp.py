@@ -86,7 +86,7 @@ class WGAN_GP(GAN):
           out=torch.zeros(7, dtype=torch.float32, device=dev))
       st['critic'].coef.copy_(torch.tensor([-1.0 / B, 1.0 / B, 1.0]))
       st['critic'].bias_coef.copy_(torch.tensor([-1.0 / B, 1.0 / B, 0.0]))
-      st['critic'].build_jvp(2)
+      st['critic'].build_jvp(2, st['coef_gp'])
       st['gen'].coef.copy_(torch.tensor([-1.0 / B]))
       st['gen'].bias_coef.zero_()
       if self.dis_optimizer.loss_scale is not None:
@@ -213,9 +213,19 @@ class WGAN_GP(GAN):
     plan = st['critic']
     s = nets._stream()
     n = lay.lin * lay.cinp
-    # v = lambda * dgp/dg, written over the x^ segment of X0
-    _lib.call('cg_scale_rows', nets._p(plan.gin), nets._p(st['coef_gp']),
-              nets._p(st['dws'].act[0][2 * B:]), B, n, s)
+    if plan.jvp_folds:
+      # g already sits over the x^ segment of X0; v = lambda * dgp/dg = coef_b * g
+      # enters the tangent chain as a per-sample scale of its first launch and
+      # the layer-1 weight gradient through delta_1's x^ segment (g (x) coef
+      # delta == coef g (x) delta): a pass over 1/4 of the bytes
+      d1 = st['dws'].delta[1][2 * B:3 * B]
+      _lib.call('cg_scale_rows', nets._p(d1), nets._p(st['coef_gp']), nets._p(d1),
+                B, d1[0].numel(), s)
+    else:
+      # v = lambda * dgp/dg, written over the x^ segment of X0 (in place when g
+      # already sits there)
+      _lib.call('cg_scale_rows', nets._p(plan.gin), nets._p(st['coef_gp']),
+                nets._p(st['dws'].act[0][2 * B:]), B, n, s)
     plan.jvp_forward()
     net_d.params.grad.zero_()
     # bias gradients: real + fake segments only (the penalty has none)

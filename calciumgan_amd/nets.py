@@ -207,13 +207,16 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
                seg_size=1, epilogue=_lib.EPI_NONE, out_f32=False, nphase=1,
                w_phase_stride=0, off_phase_step=0, yoff_phase_step=0,
                rowsumsq=None, w_parity_major=False, ln=None, out_shifts=None,
-               w_narrow_last=False, alpha=LEAKY_ALPHA):
+               w_narrow_last=False, alpha=LEAKY_ALPHA, row_scale=None):
   d = ConvDesc()
   d.w_parity_major = int(bool(w_parity_major) and stride == 2)
   d.w_narrow_last = int(bool(w_narrow_last) and d.w_parity_major)
   d.split_parity = 0
   d._keep = (x, w, y, bias, mask_src, shifts, rowsumsq)  # borrowed pointers
   d.rowsumsq = rowsumsq.data_ptr() if rowsumsq is not None else None
+  d.row_scale = row_scale.data_ptr() if row_scale is not None else None
+  if row_scale is not None:
+    d._keep = d._keep + (row_scale,)
   d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
   d.bias = bias.data_ptr() if bias is not None else None
   d.mask_src = mask_src.data_ptr() if mask_src is not None else None
@@ -237,7 +240,8 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
   d.ksplit = 0
   nchunks = Cx // CK
   if (_SPLIT_K and x.is_cuda and not out_f32 and rowsumsq is None and
-      ln is None and out_shifts is None and nchunks % 2 == 0 and
+      ln is None and out_shifts is None and row_scale is None and
+      nchunks % 2 == 0 and
       epilogue in (_lib.EPI_NONE, _lib.EPI_LRELU, _lib.EPI_MASK) and
       nB * Lu * n_tiles_n * nphase <= _SPLIT_K_MAX_TILES * 64):
     # few output tiles (the tangent chain's single segment): let the tuner try
@@ -268,6 +272,10 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
   return d
 
 
+# CALCIUMGAN_FOLD_SCALE=0: the penalty's v = coef_b * g as its own pass over g
+# (cg_scale_rows into X0) instead of a per-sample scale in the tangent chain's
+# first launch + a pass over the x^ segment of delta_1
+_FOLD_SCALE = __import__('os').environ.get('CALCIUMGAN_FOLD_SCALE', '1') != '0'
 # Split-K candidates of the tile tuner (CALCIUMGAN_SPLIT_K=0: never): only for
 # launches whose output is at most this many 64x64 tiles
 _SPLIT_K = __import__('os').environ.get('CALCIUMGAN_SPLIT_K', '1') != '0'
@@ -349,6 +357,8 @@ def _autotune_tile(d):
   key = (d.stride, d.taps, d.nB, d.Lx, d.Cx, d.Lu, d.N, d.CK, d.nphase,
          d.epilogue, d.out_f32, d.w_narrow_last, int(bool(d.rowsumsq)),
          int(bool(d.out_shifts)), int(bool(d.split_ws)), _precision_tag())
+  if d.row_scale:  # (appended only when set: saved tables keep their keys)
+    key = key + (1,)
   from . import parallel
   multi = parallel.world_size() > 1
   best = _TILE_CACHE.get(key)
@@ -751,9 +761,15 @@ class _DisPlan(object):
       nG = nB - input_grad_from
       self.nG = nG
       # bf16 like every other activation gradient (its f32 sum of squares,
-      # the penalty norm, is taken in the producing launch's epilogue)
-      self.gin = torch.zeros(nG, lay.lin, lay.cinp, dtype=act_dtype(),
-                             device=dev)
+      # the penalty norm, is taken in the producing launch's epilogue).  When a
+      # tangent chain follows (the critic's x^ segment) it is written straight
+      # over that segment of X0 -- x^ is dead once layer 1 has run forward --
+      # where the chain's first launch and the layer-1 weight gradient read it
+      # (_FOLD_SCALE: no separate pass that scales it by the penalty's coef_b)
+      self.gin_in_x0 = _FOLD_SCALE and input_grad_from > 0
+      self.gin = (ws.act[0][input_grad_from:nB] if self.gin_in_x0 else
+                  torch.zeros(nG, lay.lin, lay.cinp, dtype=act_dtype(),
+                              device=dev))
       # penalty norm fused into this launch's epilogue when a 256-row tile
       # never spans two samples; else the standalone cg_rownorm is used
       self.sumsq = None
@@ -767,25 +783,42 @@ class _DisPlan(object):
           off_phase_step=net.dgrad_offs[1] - net.dgrad_offs[0],
           yoff_phase_step=1, rowsumsq=self.sumsq)
 
-  def build_jvp(self, seg_index):
+  def build_jvp(self, seg_index, coef=None):
     """Tangent-forward chain (gradient-penalty second backward) over segment
-    seg_index, in place over that segment's activations."""
+    seg_index, in place over that segment's activations.  coef (f32 per sample
+    of the segment): the chain starts from v = coef_b * g; with the input
+    gradient g sitting in X0 (gin_in_x0) the first launch reads g and applies
+    coef_b in its epilogue (cg_conv_desc.row_scale)."""
     ws, net = self.ws, self.ws.net
+    fold = coef is not None and getattr(self, 'gin_in_x0', False)
     s0 = seg_index * self.seg_size
     n = min(self.seg_size, self.nB - s0)
     k, pl = net.k, net.pl
-    self.jvp = []
-    for i, lay in enumerate(net.layers):
-      sh = self.shifts[i - 1][seg_index:] if i > 0 else None
-      op = net.w_fwd[i]
-      seg_act = ws.act[i + 1][s0:s0 + n]
-      self.jvp.append(
-          _conv_desc(ws.act[i][s0:s0 + n], op.buf, seg_act, n, lay.lin,
-                     lay.cinp, k, 2, -pl, lay.lout, lay.cout, lay.lout,
-                     lay.coutp, op.CK, mask_src=seg_act, shifts=sh,
-                     seg_size=n, epilogue=_lib.EPI_MASK,
-                     w_parity_major=op.parity_major,
-                     w_narrow_last=op.narrow_last, alpha=net.alpha))
+    lib = _lib.load()
+
+    def build(fold_first):
+      descs = []
+      for i, lay in enumerate(net.layers):
+        sh = self.shifts[i - 1][seg_index:] if i > 0 else None
+        op = net.w_fwd[i]
+        seg_act = ws.act[i + 1][s0:s0 + n]
+        descs.append(
+            _conv_desc(ws.act[i][s0:s0 + n], op.buf, seg_act, n, lay.lin,
+                       lay.cinp, k, 2, -pl, lay.lout, lay.cout, lay.lout,
+                       lay.coutp, op.CK, mask_src=seg_act, shifts=sh,
+                       seg_size=n, epilogue=_lib.EPI_MASK,
+                       w_parity_major=op.parity_major,
+                       w_narrow_last=op.narrow_last, alpha=net.alpha,
+                       row_scale=coef if (fold_first and i == 0) else None))
+      return descs
+
+    self.jvp = build(fold)
+    # (only the software-pipelined tiles carry the per-sample scale: 24-tap
+    # kernels on the GPU; otherwise v is formed by its own pass, as before)
+    self.jvp_folds = bool(fold and ws.act[0].is_cuda and
+                          lib.cg_swconv_check(ctypes.byref(self.jvp[0])) == 0)
+    if fold and not self.jvp_folds:
+      self.jvp = build(False)
 
   # -- schedules ------------------------------------------------------------
   def forward(self):

