@@ -151,6 +151,55 @@ def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp):
                                   ref.numpy())
 
 
+@pytest.mark.parametrize('epi', [_lib.EPI_NONE, _lib.EPI_MASK])
+@pytest.mark.parametrize('tile', sorted(_lib.SWP_TILES))
+@pytest.mark.parametrize('nB,L,Ci,Co,k', [(5, 512, 102, 64, 24),
+                                          (3, 128, 64, 128, 24)])
+def test_conv_fwd_row_scale(tile, nB, L, Ci, Co, k, epi):
+  """cg_conv_desc.row_scale: y = epi((acc + bias) * row_scale[sample]) on the
+  software-pipelined tiles -- the penalty's v = coef_b * g folded into the
+  tangent chain's first launch.  Power-of-two scales on small-integer data:
+  bit-exact against the convolution of the pre-scaled input; the classic tiles,
+  split-K and the fused LayerNorm refuse the field."""
+  rng = np.random.RandomState(11)
+  x = H.int_tensor(rng, (nB, L, Ci))
+  W = H.int_tensor(rng, (k, Ci, Co), -2, 2, 0.5)
+  b = H.int_tensor(rng, (Co,), -4, 4)
+  scale = torch.tensor(2.0 ** rng.randint(-3, 3, size=nB), dtype=torch.float32)
+  scale[1] = -scale[1]
+  lin = O.conv1d_same(x, W, b, 2) * scale[:, None, None]
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  Lo = L // 2
+  pl = geo.same_padding_left(k, 2)
+  ck = nets._ck_for(cip, 2, k, Lo)
+  op = H.pack(W.to(H.DEV), [(0, 1, Ci * Co, Co, 1)], Ci, Co, cip, ck, k,
+              parity_major=True)
+  xd = H.to_pitch(x, cip)
+  y = torch.full((nB, Lo, cop), 7.0, dtype=BF16, device=H.DEV)
+  mask = None
+  ref = lin
+  if epi == _lib.EPI_MASK:
+    m = H.int_tensor(rng, (nB, Lo, Co), -1, 1)
+    mask = H.to_pitch(m, cop)
+    ref = lin * torch.where(m > 0, 1.0, nets.LEAKY_ALPHA)
+  sd = scale.to(H.DEV)
+  d = H.conv_desc(xd, op.buf, y, nB, L, cip, k, 2, -pl, Lo, Co, Lo, cop, ck,
+                  bias=b.to(H.DEV), epilogue=epi, mask_src=mask,
+                  w_parity_major=True, w_narrow_last=op.narrow_last,
+                  row_scale=sd)
+  _force_tile(d, tile, 2, 0)
+  H.sync()
+  got = y.float().cpu()
+  np.testing.assert_array_equal(got[:, :, :Co].numpy(),
+                                ref.to(BF16).float().numpy())
+  if cop > Co:
+    assert float(got[:, :, Co:].abs().max()) == 0.0
+  lib = _lib.load()
+  d.tile = 0                                   # a classic tile
+  assert lib.cg_swconv_check(ctypes.byref(d)) == _lib.CG_EINVAL
+  assert lib.cg_swconv(ctypes.byref(d), H.stream()) == _lib.CG_EINVAL
+
+
 @pytest.mark.parametrize('ksplit', [2, 4])
 @pytest.mark.parametrize('tile', [0, 1, 2, 4, 8, 9, 10, 11, 12, 13, 14, 15])
 @pytest.mark.parametrize('nB,L,Ci,Co,k,epi', [(3, 256, 128, 192, 24, 1),
