@@ -54,6 +54,41 @@ struct SwpArgs {
 constexpr int kSwpRing = 3;       // weight ring depth
 constexpr int kSwpTapsPerPass = 12;  // 24-tap stride-2 / 12-tap stride-1 windows
 
+// -DCG_SWP_TRACE (tools/swp_trace.sh; never in the product library): every wave
+// adds up the shader-clock cycles it spends in each part of the tile loop and
+// leaves them in g_swp_trace[workgroup][wave][part] (cg_debug_swp_trace reads
+// them back).  A stamp is s_memtime + s_waitcnt lgkmcnt(0), placed only where
+// the wave has no LDS read in flight.
+#ifdef CG_SWP_TRACE
+constexpr int kTraceParts = 10;
+__device__ unsigned g_swp_trace[1024 * 8 * kTraceParts];
+// (32-bit cycle counts: a wave lives well under 2^32 cycles, and ten 64-bit
+// accumulators would push the kernel's scalar registers into spills)
+#define CG_TR_DECL unsigned tr_[kTraceParts] = {}; unsigned tr_t = 0
+#define CG_TR_START tr_t = tr_now()
+#define CG_TR(part) do { const unsigned n_ = tr_now(); tr_[part] += n_ - tr_t; tr_t = n_; } while (0)
+__device__ __forceinline__ unsigned tr_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return (unsigned)t;
+}
+#else
+#define CG_TR_DECL
+#define CG_TR_START
+#define CG_TR(part)
+#endif
+
+// A wave-uniform value back in a scalar register.  The compiler computes integer
+// divisions and 64-bit products on the vector ALU; a buffer resource built from
+// such a value (a tile's sample index -> the window's base pointer) then sits in
+// VECTOR registers and every DMA that uses it is wrapped in a waterfall loop
+// (4 v_readfirstlane + 2 v_cmp + s_and_saveexec + branch -- round 2's kernels
+// had one around each of their LDS-DMA issues).  readfirstlane of the quotient /
+// of both pointer halves keeps the resource scalar.
+__device__ __forceinline__ int to_sgpr(int v) {
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
 __device__ __forceinline__ int sw64(int byte) {
   // XOR-swizzle of a byte offset into a window of 64-byte rows: row bit 2
   // (address bit 8) flips chunk bit 1 (address bit 5)
@@ -138,114 +173,168 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   // ... (gridDim.x is a multiple of 8, so a workgroup keeps its XCD residue).
   // XCD-aware mapping (as swconv_kernel): the workgroups that share one row
   // tile's source window get linear ids congruent mod 8.
+  //
+  // STREAM (-DCG_SWP_STREAM, off in the product library; instantiations without
+  // a narrow pass): the tiles of a workgroup form ONE pass stream.  The last pass
+  // of tile i issues the window of tile i + 1's first pass and its first three
+  // weight stages exactly where a middle pass issues the next pass's -- into the
+  // other window buffer and the rolling ring -- so the only thing left at a tile
+  // boundary is the epilogue: no prologue DMAs queueing behind the epilogue's
+  // stores, no vmcnt(0), no extra barrier.  (A narrow pass has 4 stages: the
+  // ring slot of a stage would no longer be compile-time across tiles.)
+  // Bit-exact on every kernel test, and 0.8 % SLOWER on the cfg2 step
+  // (tools/ab_stream.sh, profiles/r03_swp_wave_cycles.txt): the boundary is the
+  // epilogue's store burst -- 17 MB from all workgroups at once, 3.7 us -- and
+  // vmcnt retires in order, so the first stage boundary of the next tile waits
+  // for those stores whether the loads were prefetched or not.
+#ifdef CG_SWP_STREAM
+  constexpr bool STREAM = !NRW;
+#else
+  constexpr bool STREAM = false;
+#endif
   auto tile_bm = [&](int lin) { return ((lin >> 3) / gnp) * 8 + (lin & 7); };
   auto next_tile = [&](int lin) {
     while (lin < pa.ntl && tile_bm(lin) >= a.gm) lin += (int)gridDim.x;
     return lin;
   };
-  // per-tile state of the K loop (recomputed by setup_tile)
+  // what the K loop and the epilogue need of a tile (all wave-uniform)
+  struct TileS {
+    int m0, n0, y_off, b0, u00, off;
+    int wtile;  // byte offset of the tile's (phase, first column) in the operand
+  };
+  auto tile_of = [&](int lin) {
+    TileS t;
+    const int jq = lin >> 3;
+    const int jm = to_sgpr(jq / gnp);
+    const int np_i = jq - jm * gnp;
+    const int bm = jm * 8 + (lin & 7);
+    const int phase = to_sgpr(np_i / a.gn);
+    const int bn = np_i - phase * a.gn;
+    t.off = a.off + phase * a.off_phase_step;
+    t.y_off = a.y_off + phase * a.yoff_phase_step;
+    t.m0 = bm * TM;
+    t.n0 = bn * TN;
+    t.b0 = to_sgpr(t.m0 / a.Lu);      // first sample of the tile
+    t.u00 = t.m0 - t.b0 * a.Lu;       // its first output row (nseg == 1)
+    t.wtile = (int)(((long long)phase * a.w_phase_stride +
+                     (long long)t.n0 * a.Kpack) * 2);
+    return t;
+  };
+  // per-tile state of the K loop
   int m0 = 0, n0 = 0, y_off = 0, b0 = 0;
+  CG_TR_DECL;
   // source rows of this lane's window pieces, packed: bits [0, 14) the row of
   // source-row parity 0, [14, 28) of parity 1 (kRowPad = zero padding), [28, 31)
   // the sample of the tile (one register per piece instead of a byte offset per
   // parity: the 128-register tiles have none to spare)
   constexpr uint32_t kRowPad = 0x3fffu;
   uint32_t arow[KPW];
-  int boff[NBW];
   int bstage = 0;
+  int wbuf = 0;      // window buffer of the running pass
   __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(a.x), 0, 0x7fffffff, 0x00020000);
-  __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(a.w), 0, 0x7fffffff, 0x00020000);
+  // weight stages: wave w issues pieces w*NBW + i of a stage: lane L lands at
+  // slot byte piece*1024 + L*16 = (row, chunk slot c') and fetches chunk
+  // c' ^ swz(row) of that row of the tile (tile, phase and stage are the scalar
+  // offset: these per-lane offsets hold for the whole launch; columns past N
+  // stay inside the operand, which is padded to 128 rows)
+  int boff[NBW];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    const int pe = ((wave * NBW + i) * 1024 + lane * 16) / 2;  // element offset
+    const int row = pe / kRowB;
+    const int cs = (pe % kRowB) / 8;
+    const int c = cs ^ ((row >> 1) & 7);
+    boff[i] = (int)(((long long)row * a.Kpack + c * 8) * 2);
+  }
 
-  // Everything the K loop needs of tile `lin`.  Window pieces: piece j of the
-  // window of pass p -> buffer p & 1, bytes [j KiB, (j+1) KiB): lane L lands on
-  // (row 16 j + L/4, slot L & 3) and fetches the chunk that slot holds after
-  // the swizzle.  Wave w owns pieces j = k NW + w; the source offset of (k,
-  // source-row parity) at channel chunk 0 is computed ONCE per tile (the hot
-  // loop only passes the chunk offset as the scalar operand).
-  auto setup_tile = [&](int lin) {
+  // Window pieces: piece j of a pass's window -> bytes [j KiB, (j+1) KiB) of its
+  // buffer: lane L lands on (row 16 j + L/4, slot L & 3) and fetches the chunk
+  // that slot holds after the swizzle.  Wave w owns pieces j = k NW + w.  The
+  // packed source rows of piece slot k for tile t (rows counted from the tile's
+  // first sample; padding rows become an offset past num_records at issue time:
+  // the buffer form of the DMA then fetches zeros, so there is no zero page and
+  // no 64-bit select in the loop):
+  auto row_word = [&](int k, int tb0, int tu00, int toff) {
     // (lane ids re-derived from an opaque copy of the thread id: nothing of this
     // block then stays in registers across the K loop)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int jq = lin >> 3;
-    const int np_i = jq % gnp;
-    const int bm = (jq / gnp) * 8 + (lin & 7);
-    const int bn = np_i % a.gn;
-    const int phase = np_i / a.gn;
-    const uint16_t* __restrict__ wp = a.w + (long long)phase * a.w_phase_stride;
-    const int off = a.off + phase * a.off_phase_step;
-    y_off = a.y_off + phase * a.yoff_phase_step;
-    m0 = bm * TM;
-    n0 = bn * TN;
-    b0 = m0 / a.Lu;                         // first sample of the tile
-    const int u00 = m0 - b0 * a.Lu;         // its first output row (nseg == 1)
-    // per-sample phase shifts of the tile's segments
-    if (a.shifts != nullptr && tid < a.nseg) {
-      const int b = b0 + tid;
-      sh_lds[tid] = b < a.nB ? a.shifts[b / a.seg_size] : 0;
+    tb0 = to_sgpr(tb0);
+    tu00 = to_sgpr(tu00);
+    toff = to_sgpr(toff);
+    const int row = (k * NW + wave) * 16 + (lane >> 2);
+    int seg = 0;
+    if (a.nseg > 1) seg = __float2int_rz(((float)row + 0.5f) * pa.inv_WRs);
+    const int wr = row - seg * pa.WRs;
+    const int b = tb0 + seg;
+    const int u0 = a.nseg > 1 ? 0 : tu00;
+    // per-sample phase shift of the lane's segment: scalar loads (a vector load
+    // here would put an s_waitcnt vmcnt(0) -- every DMA in flight -- in the loop)
+    int sft = 0;
+    if (a.shifts != nullptr) {
+      for (int q = 0; q < a.nseg; ++q) {
+        const int bq = tb0 + q;
+        const int sq = bq < a.nB ? a.shifts[bq / a.seg_size] : 0;
+        sft = seg == q ? sq : sft;
+      }
     }
-    __syncthreads();
-    // (rows counted from the tile's first sample; padding rows become an offset
-    // past num_records at issue time: the buffer form of the DMA then fetches
-    // zeros, so there is no zero page and no 64-bit select in the loop)
+    uint32_t w = (uint32_t)seg << 28;
+#pragma unroll
+    for (int par = 0; par < R; ++par) {
+      uint32_t rr = kRowPad;
+      if (row < pa.wrows && b < a.nB) {
+        int srow = R * (u0 + wr) + toff + par;
+        if (srow >= 0 && srow < a.Lx) {
+          if (a.shifts) srow = shuffle_src(srow, sft, a.Lx);
+          rr = (uint32_t)srow;
+        }
+      }
+      w |= rr << (14 * par);
+    }
+    return w;
+  };
+  // (window rows are addressed from the tile's first sample)
+  auto x_rsrc = [&](int tb0) {
+    // (the 64-bit product is computed on the vector ALU: both halves of the
+    // pointer go back to scalar registers)
+    const unsigned long long p = reinterpret_cast<unsigned long long>(
+        a.x + (long long)tb0 * a.Lx * a.Cx);
+    const unsigned lo = (unsigned)to_sgpr((int)(unsigned)p);
+    const unsigned hi = (unsigned)to_sgpr((int)(unsigned)(p >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<uint16_t*>(((unsigned long long)hi << 32) | lo), 0,
+        0x7fffffff, 0x00020000);
+  };
+  // Everything the K loop needs of tile t (the row words of its window pieces
+  // are computed ONCE per tile; the hot loop only passes the chunk offset as the
+  // scalar operand).
+  auto setup_tile = [&](const TileS& t) {
+    m0 = t.m0;
+    n0 = t.n0;
+    y_off = t.y_off;
+    b0 = t.b0;
 #pragma unroll
     for (int k = 0; k < KPW; ++k) {
-      const int row = (k * NW + wave) * 16 + (lane >> 2);
-      int seg = 0;
-      if (a.nseg > 1) seg = __float2int_rz(((float)row + 0.5f) * pa.inv_WRs);
-      const int wr = row - seg * pa.WRs;
-      const int b = b0 + seg;
-      const int u0 = a.nseg > 1 ? 0 : u00;
-      const int sft = a.shifts != nullptr && seg < a.nseg ? sh_lds[seg] : 0;
-      uint32_t w = (uint32_t)seg << 28;
-#pragma unroll
-      for (int par = 0; par < R; ++par) {
-        uint32_t rr = kRowPad;
-        if (row < pa.wrows && b < a.nB) {
-          int srow = R * (u0 + wr) + off + par;
-          if (srow >= 0 && srow < a.Lx) {
-            if (a.shifts) srow = shuffle_src(srow, sft, a.Lx);
-            rr = (uint32_t)srow;
-          }
-        }
-        w |= rr << (14 * par);
-      }
-      if constexpr (ALDS) arow_lds[k * (NW * 64) + tid] = w;
+      const uint32_t w = row_word(k, t.b0, t.u00, t.off);
+      if constexpr (ALDS) arow_lds[k * (NW * 64) + (int)threadIdx.x] = w;
       else arow[k] = w;
     }
-    rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(a.x + (long long)b0 * a.Lx * a.Cx), 0, 0x7fffffff,
-        0x00020000);
-    // weight stages: wave w issues pieces w*NBW + i of a stage: lane L lands at
-    // slot byte piece*1024 + L*16 = (row, chunk slot c') and fetches chunk
-    // c' ^ swz(row)
-    rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wp), 0,
-                                           0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-      const int pe = ((wave * NBW + i) * 1024 + lane * 16) / 2;  // element offset
-      int row = pe / kRowB;
-      const int cs = (pe % kRowB) / 8;
-      const int c = cs ^ ((row >> 1) & 7);
-      row += n0;
-      if (row >= pa.npad_rows) row = pa.npad_rows - 1;  // columns past N: unused
-      boff[i] = (row * a.Kpack + c * 8) * 2;
-    }
-    // (one running scalar offset: + one 64-deep stage per issue)
-    bstage = chunk0 * a.Fp * 16;
+    rx = x_rsrc(t.b0);
   };
-  // issue slot k of pass p (k compile-time: the row words stay in registers)
-  auto issue_a_piece = [&](int p, int k, uint32_t w) {
+  // piece slot k of a window: source rows w, channel chunk cc (narrow: the last
+  // one), source-row parity par, into window buffer `buf`
+  auto issue_a_piece = [&](__amdgpu_buffer_rsrc_t r, int buf, int cc, int par_full,
+                           bool narrow_pass, int k, uint32_t w) {
     int par, add;
     uint32_t qb;
     bool pad = false;
-    if (!NRW || p < full_passes) {
-      const int cc = R == 2 ? (p >> 1) : p;
-      par = R == 2 ? (p & 1) : 0;
+    if (!NRW || !narrow_pass) {
+      par = par_full;
       add = (chunk0 + cc) * 64;
       qb = (uint32_t)aq * 16;
     } else {
@@ -261,10 +350,15 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     uint32_t o = __umul24((w >> 28) * (uint32_t)a.Lx + rr, (uint32_t)a.Cx * 2) + qb;
     if (pad || rr == kRowPad) o = ~0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        rx,
-        (__attribute__((address_space(3))) void*)(ldsA + (p & 1) * ABYTES +
+        r,
+        (__attribute__((address_space(3))) void*)(ldsA + buf * ABYTES +
                                                   (k * NW + wave) * 1024),
         16, (int)o, add, 0, 0);
+  };
+  // window piece of pass p of the running tile (p > 0 while its predecessor runs)
+  auto issue_a_cur = [&](int p, int k, uint32_t w) {
+    const bool np = NRW && p >= full_passes;
+    issue_a_piece(rx, (wbuf ^ 1), R == 2 ? (p >> 1) : p, R == 2 ? (p & 1) : 0, np, k, w);
   };
   // piece slot K (compile-time) of pass p; returns 1 if this wave owns it
   auto issue_a_slot = [&](int p, auto k_tag) {
@@ -272,27 +366,27 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     if constexpr (K < KPW) {
       if ((K * NW + wave) < pa.npa) {
         if constexpr (ALDS)
-          issue_a_piece(p, K, arow_lds[K * (NW * 64) + (int)threadIdx.x]);
+          issue_a_cur(p, K, arow_lds[K * (NW * 64) + (int)threadIdx.x]);
         else
-          issue_a_piece(p, K, arow[K]);
+          issue_a_cur(p, K, arow[K]);
         return 1;
       }
     }
     return 0;
   };
-  // pieces k in [k0, k1) of pass p; returns how many were issued
-  auto issue_a_range = [&](int p, int k0, int k1) {
-    int n = 0;
-#pragma unroll
-    for (int k = 0; k < KPW; ++k)
-      if (k >= k0 && k < k1 && (k * NW + wave) < pa.npa) {
-        if constexpr (ALDS)
-          issue_a_piece(p, k, arow_lds[k * (NW * 64) + (int)threadIdx.x]);
-        else
-          issue_a_piece(p, k, arow[k]);
-        ++n;
+  // the same slot of the NEXT tile's first pass (STREAM): its row word is
+  // computed on the spot -- the words kept in registers / LDS are the running
+  // tile's -- and it goes into the buffer the running (last) pass does not read
+  auto issue_a_next = [&](int tb0, int tu00, int toff, auto k_tag) {
+    constexpr int K = decltype(k_tag)::value;
+    if constexpr (K < KPW) {
+      if ((K * NW + wave) < pa.npa) {
+        issue_a_piece(x_rsrc(tb0), (wbuf ^ 1), 0, 0, false, K,
+                      row_word(K, tb0, tu00, toff));
+        return 1;
       }
-    return n;
+    }
+    return 0;
   };
   auto issue_b = [&](int slot_idx) {
     uint16_t* slot = ldsB + slot_idx * kBufB;
@@ -303,9 +397,20 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
           16, boff[i], bstage, 0, 0);
     bstage += KS * 32 * 2;
   };
-  // window of pass 0 and weight stages 0..2 of the tile set up last
-  auto issue_prologue = [&]() {
-    issue_a_range(0, 0, KPW);
+  // (one running scalar offset: + one 64-deep stage per issue)
+  auto first_stage_of = [&](int wtile) { return wtile + chunk0 * a.Fp * 16; };
+  // window of pass 0 and weight stages 0..2 of the tile set up last (the first
+  // tile of a workgroup; every tile of the kernels that keep the tile boundary)
+  auto issue_prologue = [&](const TileS& t) {
+    wbuf = 1;  // (the pieces go to the buffer "after" the running one: 0)
+#pragma unroll
+    for (int k = 0; k < KPW; ++k)
+      if ((k * NW + wave) < pa.npa) {
+        if constexpr (ALDS) issue_a_cur(0, k, arow_lds[k * (NW * 64) + (int)threadIdx.x]);
+        else issue_a_cur(0, k, arow[k]);
+      }
+    wbuf = 0;
+    bstage = first_stage_of(t.wtile);
     issue_b(0);
     if (pa.total_stages > 1) issue_b(1);
     if (pa.total_stages > 2) issue_b(2);
@@ -407,15 +512,24 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   // Per stage: [reads of K-step 1 | MFMAs of K-step 0] counted wait + barrier
   // (publishes stage gs + 1, frees slot gs and the other window buffer)
   // [reads of the next stage's K-step 0 | DMA issue | MFMAs of K-step 1].
+  // (STREAM: the tile after the running one and its window resource; stream_next:
+  // there is one, so the running tile's last pass behaves like a middle pass)
+  // (plain wave-uniform ints, made scalar again at every use: as a struct behind
+  // the lambdas' references they went through private memory and came back as
+  // per-lane values -- a waterfall loop around every DMA)
+  int n_m0 = 0, n_n0 = 0, n_yoff = 0, n_b0 = 0, n_u00 = 0, n_off = 0, n_wtile = 0;
+  bool stream_next = false;
   auto run_pass = [&](auto narrow_tag, int p) {
     constexpr bool NARROW = decltype(narrow_tag)::value;
     // only in the final pass of the tile can a later weight stage be missing
-    // (every other pass is followed by at least 4 stages)
+    // (every other pass is followed by at least 4 stages) -- and with a next
+    // tile in the stream not even there
     const bool last = p + 1 == pa.npass;
+    const bool ends = last && !(STREAM && stream_next);
     constexpr int NSTG = NARROW ? 4 : NST;
     const bool next_narrow = NRW && p + 1 >= full_passes;  // (the pass after, if any)
-    const int cur_off = (p & 1) * ABYTES;
-    const int delta = (p & 1) ? -ABYTES : ABYTES;
+    const int cur_off = wbuf * ABYTES;
+    const int delta = wbuf ? -ABYTES : ABYTES;
     int na_prev = 0;
     static_for<NSTG>([&](auto s_tag) {
       constexpr int s = decltype(s_tag)::value;
@@ -432,14 +546,17 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       }
       mfma_step(af0, bf0);
       lds_wait();
+      CG_TR(0);  // first half: reads of K-step 1, MFMAs of K-step 0
       // ---- stage boundary ---------------------------------------------------
       // (window pieces are only issued in stages 0 .. NSTG - 3: none can be in
       // flight at the boundaries of stage 0 and of the last stage)
       if constexpr (s == 0 || s == NSTG - 1 || NARROW)
-        wait_stage(!last || s + 2 < NSTG, 0);
+        wait_stage(!ends || s + 2 < NSTG, 0);
       else
-        wait_stage(!last || s + 2 < NSTG, na_prev);
+        wait_stage(!ends || s + 2 < NSTG, na_prev);
+      CG_TR(1);  // counted vmcnt wait
       __builtin_amdgcn_s_barrier();
+      CG_TR(2);  // barrier
       // ---- second half ------------------------------------------------------
       if constexpr (s + 1 < NSTG) {
         read_b(bf0, SLOT1{}, I0{});
@@ -456,9 +573,15 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       }
       // (the DMA issue sits behind the reads: in front of them the LDS pipe and
       // the matrix pipe both idle while the wave builds addresses)
-      if (!last || s + 3 < NSTG) issue_b(s % kSwpRing);
+      if constexpr (STREAM && s == NSTG - 3) {
+        // the stream's stage s + 3 is the next tile's first
+        if (last && stream_next)
+          bstage = first_stage_of(to_sgpr(n_wtile));
+      }
+      if (!ends || s + 3 < NSTG) issue_b(s % kSwpRing);
       mfma_step(af1, bf1);
       lds_wait();
+      CG_TR(3);  // second half: reads, weight DMA issue, MFMAs of K-step 1
       // window of the next pass: stages 0 .. NSTG - 3 of this pass, so the wait
       // of stage NSTG - 1 (which leaves only the previous stage's pieces in
       // flight) retires all of them before the first read.  (Behind the MFMA
@@ -473,11 +596,21 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
             na_prev = issue_a_slot(p + 1, integral_constant<int, 2 * s>{}) +
                       issue_a_slot(p + 1, integral_constant<int, 2 * s + 1>{});
           }
+        } else if (STREAM && stream_next) {
+          if (pa.apw == 1) {
+            na_prev = issue_a_next(n_b0, n_u00, n_off, integral_constant<int, s>{});
+          } else {
+            na_prev =
+                issue_a_next(n_b0, n_u00, n_off, integral_constant<int, 2 * s>{}) +
+                issue_a_next(n_b0, n_u00, n_off, integral_constant<int, 2 * s + 1>{});
+          }
         }
       }
+      CG_TR(4);  // window DMA issue
     });
 #pragma unroll
     for (int t = 0; t < NAA; ++t) aaddr[t] += delta;
+    wbuf ^= 1;
   };
   using False = integral_constant<bool, false>;
   using True = integral_constant<bool, true>;
@@ -724,38 +857,77 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   // ---- the tile loop -----------------------------------------------------------
   int lin = next_tile((int)blockIdx.x);
   if (lin >= pa.ntl) return;
-  setup_tile(lin);
-  issue_prologue();
+  CG_TR_START;
+  {
+    const TileS t0 = tile_of(lin);
+    setup_tile(t0);
+    issue_prologue(t0);
+  }
+  CG_TR(7);  // tile set-up + prologue DMA issue
+  bool landed = false;  // the tile's first window and weight stages are published
   while (true) {
+    const int lin_next = next_tile(lin + (int)gridDim.x);
+    if constexpr (STREAM) {
+      stream_next = lin_next < pa.ntl;
+      if (stream_next) {
+        const TileS t = tile_of(lin_next);
+        n_m0 = t.m0, n_n0 = t.n0, n_yoff = t.y_off, n_b0 = t.b0, n_u00 = t.u00;
+        n_off = t.off, n_wtile = t.wtile;
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // window of pass 0 and weight stages 0..2 have landed (and the stores of the
-    // previous tile's epilogue have been taken)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!landed) {
+      // window of pass 0 and weight stages 0..2 have landed (and the stores of
+      // the previous tile's epilogue have been taken)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      CG_TR(5);  // prologue wait: first window + three weight stages (+ old stores)
+      __builtin_amdgcn_s_barrier();
+    }
     read_b(bf0, I0{}, I0{});
     read_a(af0, (!NRW || full_passes > 0) ? aaddr[0] : naddr(0, 0, 0), X0{});
     lds_wait();
+    CG_TR(6);  // prologue barrier + first fragment reads
     for (int p = 0; p < full_passes; ++p) run_pass(False{}, p);
     if constexpr (NRW) run_pass(True{}, full_passes);
-    // (the tap addresses toggle window buffers per pass: back to buffer 0)
-    if (pa.npass & 1) {
-#pragma unroll
-      for (int t = 0; t < NAA; ++t) aaddr[t] -= ABYTES;
-    }
-    // epilogue of this tile, then -- its stores still in flight -- the DMAs of
-    // the next tile's prologue: the two bursts share the memory system instead
-    // of queueing behind a workgroup launch
     const int em0 = m0, en0 = n0, ey_off = y_off, eb0 = b0;
     epilogue(em0, en0, ey_off, eb0);
-    lin = next_tile(lin + (int)gridDim.x);
+    CG_TR(8);  // epilogue
+    lin = lin_next;
     if (lin >= pa.ntl) break;
-    // (every wave is past the last LDS read of the K loop: setup_tile's barrier)
-    setup_tile(lin);
-    issue_prologue();
+    if constexpr (STREAM) {
+      // the stream already holds this tile's first window and weight stages
+      // (published by the last stage boundary of the pass just run)
+      TileS t;
+      t.m0 = n_m0, t.n0 = n_n0, t.y_off = n_yoff, t.b0 = n_b0, t.u00 = n_u00;
+      t.off = n_off, t.wtile = n_wtile;
+      setup_tile(t);
+      landed = true;
+    } else {
+      // (the tap addresses toggle window buffers per pass: back to buffer 0)
+      if (wbuf) {
+#pragma unroll
+        for (int t = 0; t < NAA; ++t) aaddr[t] -= ABYTES;
+        wbuf = 0;
+      }
+      // its stores still in flight, the DMAs of the next tile's prologue (every
+      // wave is past the last LDS read of the K loop behind this barrier)
+      __builtin_amdgcn_s_barrier();
+      const TileS t = tile_of(lin);
+      setup_tile(t);
+      issue_prologue(t);
+    }
+    CG_TR(7);
   }
+#ifdef CG_SWP_TRACE
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024 && blockIdx.y == 0) {
+    tr_[9] = tr_now();  // (end stamp: skew between workgroups)
+    for (int k = 0; k < kTraceParts; ++k)
+      g_swp_trace[((int)blockIdx.x * 8 + (int)(threadIdx.x >> 6)) * kTraceParts + k] = tr_[k];
+  }
+#endif
 }
 
 // (the body is a __device__ function: with the buffer-resource builtins written
@@ -826,6 +998,14 @@ int launch_swp(const SwpArgs& pa, unsigned gy, size_t lds, bool dry, hipStream_t
 }
 
 }  // namespace
+
+#ifdef CG_SWP_TRACE
+extern "C" int cg_debug_swp_trace(unsigned* dst, int n) {
+  if (n > 1024 * 8 * kTraceParts) return CG_EINVAL;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_swp_trace),
+                                  (size_t)n * sizeof(unsigned));
+}
+#endif
 
 int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
                       int ksplit, bool dry, hipStream_t stream) {
