@@ -857,6 +857,26 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   // ---- the tile loop -----------------------------------------------------------
   int lin = next_tile((int)blockIdx.x);
   if (lin >= pa.ntl) return;
+#ifndef CG_SWP_NO_STAGGER
+  // Start stagger.  All resident workgroups run equal tiles in lockstep, so every
+  // tile boundary is a chip-wide burst (the epilogue's stores: 17 MB in 3.7 us,
+  // profiles/r03_swp_wave_cycles.txt) during which no MFMA issues.  Four start
+  // phases 3 200 cycles apart -- the two workgroups that share a CU (ids 256
+  // apart) and neighbouring ids (bit 0) -- spread each burst while the other
+  // workgroup of the CU computes; the price is the same delay once at the end
+  // of the launch.  Measured on the cfg2 step (tools/ab_stagger.sh, three boxes):
+  // -1.0 ... -1.7 %; less at 1 920 or 5 120 cycles per phase, a loss with eight
+  // phases or with phases of a quarter tile, and nothing when only the
+  // multi-tile or only the single-tile launches are staggered.
+#ifndef CG_SWP_STAGGER
+#define CG_SWP_STAGGER (((bx & 1) + 2 * ((bx >> 8) & 1)) * 5)
+#endif
+  {
+    const int bx = (int)blockIdx.x;
+    const int st = CG_SWP_STAGGER;  // units of s_sleep 10 = 640 cycles
+    for (int i = 0; i < st; ++i) __builtin_amdgcn_s_sleep(10);
+  }
+#endif
   CG_TR_START;
   {
     const TileS t0 = tile_of(lin);
