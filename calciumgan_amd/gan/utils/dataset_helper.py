@@ -119,12 +119,30 @@ def cache_validation_set(hparams, validation):
   if os.path.exists(hparams.validation_cache):
     return
   sig = validation['signals']
+  spikes = validation['spikes']
+  keep = validated_samples(len(sig), hparams.batch_size,
+                           getattr(hparams, 'world_size', 1))
+  if len(keep) != len(sig):
+    sig, spikes = sig[keep], spikes[keep]
   if hparams.normalize:
     sig = sig * (hparams.signals_max - hparams.signals_min) + hparams.signals_min
   h5_helper.write(hparams.validation_cache, {
       'signals': sig.astype(np.float32),
-      'spikes': validation['spikes'].astype(np.int8)
+      'spikes': spikes.astype(np.int8)
   })
+
+
+def validated_samples(num_samples, batch_size, world_size):
+  """Indices of the validation samples a run really validates, in order.  Data
+  parallel: every rank takes r::world of the largest prefix of a batch that
+  divides evenly (parallel.shard_batch), so a ragged last batch loses up to
+  world - 1 samples; generated/validation.h5 holds exactly the samples the
+  generated files have counterparts for (compute_metrics pairs them by index)."""
+  if world_size <= 1:
+    return np.arange(num_samples)
+  keep = [np.arange(s, s + (min(batch_size, num_samples - s) // world_size) *
+                    world_size) for s in range(0, num_samples, batch_size)]
+  return np.concatenate(keep) if keep else np.arange(0)
 
 
 SURROGATE_TRAIN_SIZE = 8192  # dataset_helper.py:76

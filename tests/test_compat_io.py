@@ -157,6 +157,25 @@ def test_dataset_directory_roundtrip(tmp_path):
   np.testing.assert_array_equal(order, train_ds.spikes[rows])
   # validation cache for the spike-metric scripts (dataset_helper.py:12-30)
   assert h5_helper.get(hp.validation_cache, 'spikes').dtype == np.int8
+  assert len(h5_helper.get(hp.validation_cache, 'signals')) == 6
+
+
+def test_validation_cache_holds_the_samples_a_sharded_run_validates():
+  """Data parallel: shard_batch drops the ragged tail of every batch, and the
+  cache must hold exactly the samples that get a generated counterpart."""
+  from calciumgan_amd import parallel
+  for n, bs, world in [(6, 4, 1), (6, 4, 2), (11, 4, 3), (5, 8, 4), (3, 8, 4)]:
+    keep = dataset_helper.validated_samples(n, bs, world)
+    want = []
+    for s in range(0, n, bs):
+      batch = np.arange(s, min(s + bs, n))
+      shards = [parallel.shard_batch(batch, r, world) for r in range(world)]
+      if shards[0] is None:
+        assert all(sh is None for sh in shards)
+        continue
+      # what gather_batch puts back together: sample i * world + r
+      want.extend(np.stack(shards, axis=1).reshape(-1))
+    np.testing.assert_array_equal(keep, np.asarray(want, dtype=keep.dtype))
 
 
 # ---------------------------------------------------------------------------
