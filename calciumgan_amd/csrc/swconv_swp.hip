@@ -48,6 +48,7 @@ struct SwpArgs {
   int total_stages;
   int npad_rows;     // rows of the packed operand (N rounded up to 128)
   int ntl;           // linear tile ids: gm rounded up to 8, x gn x gp
+  int bias_off;      // byte offset of the bias table in LDS (gn * TN floats)
   float inv_WRs;
 };
 
@@ -126,12 +127,13 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsA = smem;
   uint16_t* ldsB = reinterpret_cast<uint16_t*>(smem + 2 * ABYTES);
-  // behind the ring: phase shifts of the tile's segments (32 ints), the
-  // rowsumsq slots of the waves (16 floats) and, for the fused LayerNorm, the
-  // row-statistics exchange table and gamma / beta.  Nothing of the epilogue
+  // behind the ring: the rowsumsq slots of the waves (16 floats), for the fused
+  // LayerNorm the row-statistics exchange table and gamma / beta, and last the
+  // bias of every column tile (gn * TN floats, zero past N; read once per launch:
+  // as a global load in the epilogue its round trip, 2 900 cycles, sat in
+  // front of every tile's stores -- profiles/r03_swp_wave_cycles.txt).  Nothing of the epilogue
   // lives in the window / ring area: the next tile's DMAs land there meanwhile.
-  int* sh_lds = reinterpret_cast<int*>(smem + 2 * ABYTES + kSwpRing * kBufB * 2);
-  float* wsum = reinterpret_cast<float*>(sh_lds + 32);
+  float* wsum = reinterpret_cast<float*>(smem + 2 * ABYTES + kSwpRing * kBufB * 2);
   float* part = wsum + 16;                // [2][NW][16][2]
   float* lnp = part + 2 * NW * 32;        // gamma[128] | beta[128] (zero past N)
   // the 128-register stride-2 256 x 64 tile keeps the row words of its window
@@ -167,6 +169,12 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       lnp[128 + tid] = tid < a.N ? a.ln_beta[tid] : 0.f;
     }
   }
+
+  float* bias_lds = reinterpret_cast<float*>(smem + pa.bias_off);
+  for (int i = tid; i < a.gn * TN; i += NW * 64)
+    bias_lds[i] = (a.bias != nullptr && i < a.N) ? a.bias[i] : 0.f;
+  // (published by the barriers of the first tile's K loop, long before the
+  // first epilogue)
 
   // ---- tile walk ---------------------------------------------------------------
   // The workgroup is persistent: linear tile ids lin = blockIdx.x, + gridDim.x,
@@ -654,13 +662,22 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     const int nl0 = en0 + wn * 64 + cq;  // lane's first column of block pair 0
     float bv[2][8];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < 2; ++p) {
+      const f32x4 b0v = *reinterpret_cast<const f32x4*>(bias_lds + nl0 + p * 32);
+      const f32x4 b1v = *reinterpret_cast<const f32x4*>(bias_lds + nl0 + p * 32 + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int n = nl0 + p * 32 + e;
-        bv[p][e] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        bv[p][e] = b0v[e];
+        bv[p][4 + e] = b1v[e];
       }
+    }
     const int mw0 = em0 + wm * MT * 16;  // first row of this wave
+#ifdef CG_SWP_TRACE
+    for (int p = 0; p < 2; ++p)
+      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bv[p][e]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CG_TR(9);  // epilogue: until the bias values have arrived
+#endif
     if constexpr (LN) {
       // fused LayerNorm + LeakyReLU: a row's statistics span the two waves that
       // share its row block (wave ^ 1); the partial sums meet in a small LDS
@@ -943,7 +960,6 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   }
 #ifdef CG_SWP_TRACE
   if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024 && blockIdx.y == 0) {
-    tr_[9] = tr_now();  // (end stamp: skew between workgroups)
     for (int k = 0; k < kTraceParts; ++k)
       g_swp_trace[((int)blockIdx.x * 8 + (int)(threadIdx.x >> 6)) * kTraceParts + k] = tr_[k];
   }
@@ -1068,11 +1084,13 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   if (pa.npa > npa_max) return CG_EINVAL;
   // windows + weight ring + [phase shifts | rowsumsq slots]; the fused
   // LayerNorm adds its statistics table (2 x nw x 16 x 2 floats) and gamma / beta
-  size_t lds = (size_t)2 * npa_max * 1024 + (size_t)kSwpRing * tn * 64 * 2 + 128 + 64;
+  size_t lds = (size_t)2 * npa_max * 1024 + (size_t)kSwpRing * tn * 64 * 2 + 64;
   if (ln) lds += (size_t)2 * nw * 32 * 4 + 256 * 4;
   // (row words of the window pieces of the stride-2 8-wave 256 x 64 tile)
   if (stride == 2 && nw == 8 && wn == 1 && mt == 2)
     lds += (size_t)((tm / 16 + 6 + nw - 1) / nw) * nw * 64 * 4;
+  pa.bias_off = (int)lds;
+  lds += (size_t)a.gn * tn * 4;
   if (lds > 160 * 1024) return CG_EINVAL;
   pa.ntl = ((a.gm + 7) / 8) * 8 * a.gn * a.gp;
   const unsigned grid = (unsigned)(ksplit > 1 ? ksplit : 1);

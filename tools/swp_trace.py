@@ -24,7 +24,7 @@ from calciumgan_amd import _lib, geometry as geo, nets
 PARTS = ['first half (reads k1 | MFMA k0)', 'counted vmcnt wait', 'stage barrier',
          'second half (reads | W DMA | MFMA k1)', 'window DMA issue',
          'prologue vmcnt(0)', 'prologue barrier + reads', 'tile set-up + DMA issue',
-         'epilogue']
+         'epilogue after the bias arrived', 'epilogue: bias load round trip']
 
 
 def main():
@@ -73,9 +73,9 @@ def main():
   rc = lib.cg_debug_swp_trace(buf.ctypes.data, buf.size)
   assert rc == 0, rc
   t = buf.reshape(1024, 8, nparts).astype(np.float64)
-  live = t[:, :, :9].sum(-1) > 0
+  live = t[:, :, :10].sum(-1) > 0
   w = t[live]                       # (waves, parts)
-  tot = w[:, :9].sum(-1)
+  tot = w[:, :10].sum(-1)
   nchunks = Cx // CK
   narrow = 1 if op.narrow_last else 0
   stages_tile = (nchunks - narrow) * R * 6 + narrow * 4
