@@ -214,7 +214,10 @@ def main():
   B = args.batch
   data = dg.make_dataset(args.neurons, args.seq_len, num_segments=B,
                          seed=1234 + rank)
-  real = torch.from_numpy(data['signals']).to(gan.device).contiguous()
+  # the batch sits where train()'s hipGraph reads it (main.py's loader gathers
+  # every batch into the same buffer): resident in HBM before the timed region
+  real = gan.batch_buffer(B)
+  real.copy_(torch.from_numpy(data['signals']))
 
   def barrier():
     if world > 1:

@@ -21,6 +21,7 @@ class GAN(object):
     self.discriminator = discriminator
     self._summary = summary
     self.noise_shape = tuple(hparams.noise_shape)
+    self.signal_shape = tuple(hparams.signal_shape)
     self._normalize = hparams.normalize
     self._signals_min = float(getattr(hparams, 'signals_min', 0.0))
     self._signals_max = float(getattr(hparams, 'signals_max', 1.0))

@@ -60,6 +60,9 @@ class ArrayDataset(object):
     self.batch_size, self.shuffle = batch_size, shuffle
     self._rng = np.random.RandomState(seed)
     self._dev_signals = None
+    # callable(batch_len) -> device tensor to gather the batch into, or None
+    # (main.py binds the training set to WGAN_GP.batch_buffer)
+    self.gather_into = None
 
   def to_device(self, device):
     """Keep the whole signal set resident in HBM (8192 x 2048 x 102 f32 is
@@ -83,7 +86,14 @@ class ArrayDataset(object):
       if self._dev_signals is not None:
         import torch
         jj = torch.from_numpy(j).to(self._dev_signals.device)
-        yield self._dev_signals.index_select(0, jj), LazyRows(self.spikes, j)
+        out = self.gather_into(len(j)) if self.gather_into is not None else None
+        if out is not None:
+          # (the SAME tensor every step: the consumer is done with batch k
+          # before batch k + 1 is gathered -- one stream, a sequential loop)
+          torch.index_select(self._dev_signals, 0, jj, out=out)
+          yield out, LazyRows(self.spikes, j)
+        else:
+          yield self._dev_signals.index_select(0, jj), LazyRows(self.spikes, j)
       else:
         yield self.signals[j], LazyRows(self.spikes, j)
 

@@ -182,6 +182,9 @@ def main(hparams, return_metrics=False):
   utils.load_models(hparams, gan)
   # dataset resident in HBM: no per-step host-to-device copy
   train_ds.to_device(gan.device)
+  if hparams.world_size == 1 and hasattr(gan, 'batch_buffer'):
+    # batches are gathered straight into the buffer train()'s hipGraph reads
+    train_ds.gather_into = gan.batch_buffer
   validation_ds.to_device(gan.device)
 
   start = time()

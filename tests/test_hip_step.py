@@ -291,6 +291,30 @@ def test_single_pass_generator_matches_per_update_passes(monkeypatch):
   assert (diff > 2.5e-5).mean() <= 0.05
 
 
+def test_batch_buffer_feeds_the_graph_without_a_copy():
+  """WGAN_GP.batch_buffer: the buffer train()'s hipGraph reads its batch from.
+  A loader that gathers into it (main.py binds ArrayDataset.gather_into) saves
+  the copy in front of every replay; any other tensor is still copied in."""
+  hp, gen, dis, gan, real, B = _build('tiny')
+  buf = gan.batch_buffer(B)
+  assert tuple(buf.shape) == (B,) + tuple(hp.signal_shape)
+  assert buf.dtype == torch.float32 and buf.is_cuda
+  buf.copy_(torch.from_numpy(real))
+  for _ in range(4):                      # two eager calls, capture, replay
+    out = gan.train(buf)
+  torch.cuda.synchronize()
+  g = gan._get_state(B)['graph']
+  assert g is not None and g['real'].data_ptr() == buf.data_ptr()
+  assert gan.batch_buffer(B).data_ptr() == buf.data_ptr()
+  assert np.isfinite([float(out[0]), float(out[1]), float(out[2])]).all()
+  # a replay on another tensor: copied into the buffer first
+  other = torch.from_numpy(real[::-1].copy()).to(gan.device)
+  out = gan.train(other)
+  torch.cuda.synchronize()
+  assert torch.equal(buf, other)
+  assert np.isfinite([float(out[0]), float(out[1]), float(out[2])]).all()
+
+
 def test_train_dynamics_follow_f32_oracle():
   """Twenty train() calls (100 critic + 20 generator Adam updates) at the cfg1
   layer shapes on injected randomness, against the plain f32 oracle: the bf16
