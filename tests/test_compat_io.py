@@ -160,6 +160,34 @@ def test_dataset_directory_roundtrip(tmp_path):
   assert len(h5_helper.get(hp.validation_cache, 'signals')) == 6
 
 
+def test_loader_gathers_batches_into_the_bound_buffer():
+  """ArrayDataset.gather_into (main.py binds it to WGAN_GP.batch_buffer): every
+  batch of a device-resident set is gathered into the tensor the callable hands
+  out for its length -- the ragged last batch gets its own -- and holds the
+  same rows as the unbound loader's batches."""
+  import torch
+  rng = np.random.RandomState(3)
+  sig = rng.rand(10, 6, 2).astype(np.float32)
+  spk = rng.randint(0, 2, size=(10, 6, 2)).astype(np.int8)
+  plain = dataset_helper.ArrayDataset(sig, spk, 4, shuffle=True, seed=9).to_device('cpu')
+  bound = dataset_helper.ArrayDataset(sig, spk, 4, shuffle=True, seed=9).to_device('cpu')
+  buffers = {}
+
+  def buffer(n):
+    if n not in buffers:
+      buffers[n] = torch.empty((n, 6, 2), dtype=torch.float32)
+    return buffers[n]
+
+  bound.gather_into = buffer
+  seen = 0
+  for (a, sa), (b, sb) in zip(plain, bound):
+    assert b is buffers[len(b)]
+    assert torch.equal(a, b)
+    np.testing.assert_array_equal(np.asarray(sa), np.asarray(sb))
+    seen += len(b)
+  assert seen == 10 and sorted(buffers) == [2, 4]
+
+
 def test_validation_cache_holds_the_samples_a_sharded_run_validates():
   """Data parallel: shard_batch drops the ragged tail of every batch, and the
   cache must hold exactly the samples that get a generated counterpart."""
