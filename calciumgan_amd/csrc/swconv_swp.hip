@@ -834,9 +834,14 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
             }
+            // (columns past N are stored as zeros; only the last column tile of
+            // an N that is no multiple of the tile has any: a scalar branch
+            // instead of 16 compares and selects per store)
+            if (en0 + TN > a.N) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (n + e >= a.N) v[e] = 0.f;
+              for (int e = 0; e < 8; ++e)
+                if (n + e >= a.N) v[e] = 0.f;
+            }
             if (a.rowsumsq) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
