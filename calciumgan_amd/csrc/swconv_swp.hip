@@ -321,17 +321,22 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   // Everything the K loop needs of tile t (the row words of its window pieces
   // are computed ONCE per tile; the hot loop only passes the chunk offset as the
   // scalar operand).
-  auto setup_tile = [&](const TileS& t) {
+  auto store_word = [&](auto k_tag, int tb0, int tu00, int toff) {
+    constexpr int K = decltype(k_tag)::value;
+    if constexpr (K < KPW) {
+      const uint32_t w = row_word(K, tb0, tu00, toff);
+      if constexpr (ALDS) arow_lds[K * (NW * 64) + (int)threadIdx.x] = w;
+      else arow[K] = w;
+    }
+  };
+  // (words_done: the last pass of the previous tile left this tile's row words)
+  auto setup_tile = [&](const TileS& t, bool words_done) {
     m0 = t.m0;
     n0 = t.n0;
     y_off = t.y_off;
     b0 = t.b0;
-#pragma unroll
-    for (int k = 0; k < KPW; ++k) {
-      const uint32_t w = row_word(k, t.b0, t.u00, t.off);
-      if constexpr (ALDS) arow_lds[k * (NW * 64) + (int)threadIdx.x] = w;
-      else arow[k] = w;
-    }
+    if (!words_done)
+      static_for<KPW>([&](auto k_tag) { store_word(k_tag, t.b0, t.u00, t.off); });
     rx = x_rsrc(t.b0);
   };
   // piece slot k of a window: source rows w, channel chunk cc (narrow: the last
@@ -527,6 +532,24 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   // per-lane values -- a waterfall loop around every DMA)
   int n_m0 = 0, n_n0 = 0, n_yoff = 0, n_b0 = 0, n_u00 = 0, n_off = 0, n_wtile = 0;
   bool stream_next = false;
+  // The running tile, the one after it and whether there is one.  Kernels that
+  // keep the tile boundary work the next tile out INSIDE the last pass of the
+  // running one -- its id and scalars in stage 0, the row words of its window
+  // pieces (the running tile's are dead by then) in the later stages -- where
+  // the instructions issue between MFMAs the wave would wait for anyway; at the
+  // boundary they were 200-odd instructions at a quarter of the issue rate in
+  // front of the next tile's DMAs (profiles/r03_swp_wave_cycles.txt).
+  int lin = 0, lin_next = 0;
+  bool has_next = false;
+  auto plan_next = [&]() {
+    lin_next = next_tile(lin + (int)gridDim.x);
+    has_next = lin_next < pa.ntl;
+    if (has_next) {
+      const TileS t = tile_of(lin_next);
+      n_m0 = t.m0, n_n0 = t.n0, n_yoff = t.y_off, n_b0 = t.b0, n_u00 = t.u00;
+      n_off = t.off, n_wtile = t.wtile;
+    }
+  };
   auto run_pass = [&](auto narrow_tag, int p) {
     constexpr bool NARROW = decltype(narrow_tag)::value;
     // only in the final pass of the tile can a later weight stage be missing
@@ -614,7 +637,23 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
           }
         }
       }
-      CG_TR(4);  // window DMA issue
+      if constexpr (!STREAM) {
+        if (last) {
+          // words per stage: stages 1 .. NSTG - 1 share the KPW of them
+          constexpr int WPS = (KPW + NSTG - 2) / (NSTG - 1);
+          if constexpr (s == 0) {
+            plan_next();
+          } else {
+            if (has_next) {
+              static_for<WPS>([&](auto j_tag) {
+                store_word(integral_constant<int, (s - 1) * WPS + decltype(j_tag)::value>{},
+                           n_b0, n_u00, n_off);
+              });
+            }
+          }
+        }
+      }
+      CG_TR(4);  // window DMA issue (+ the next tile's row words in a last pass)
     });
 #pragma unroll
     for (int t = 0; t < NAA; ++t) aaddr[t] += delta;
@@ -877,7 +916,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   };
 
   // ---- the tile loop -----------------------------------------------------------
-  int lin = next_tile((int)blockIdx.x);
+  lin = next_tile((int)blockIdx.x);
   if (lin >= pa.ntl) return;
 #ifndef CG_SWP_NO_STAGGER
   // Start stagger.  All resident workgroups run equal tiles in lockstep, so every
@@ -902,20 +941,15 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   CG_TR_START;
   {
     const TileS t0 = tile_of(lin);
-    setup_tile(t0);
+    setup_tile(t0, false);
     issue_prologue(t0);
   }
   CG_TR(7);  // tile set-up + prologue DMA issue
   bool landed = false;  // the tile's first window and weight stages are published
   while (true) {
-    const int lin_next = next_tile(lin + (int)gridDim.x);
     if constexpr (STREAM) {
-      stream_next = lin_next < pa.ntl;
-      if (stream_next) {
-        const TileS t = tile_of(lin_next);
-        n_m0 = t.m0, n_n0 = t.n0, n_yoff = t.y_off, n_b0 = t.b0, n_u00 = t.u00;
-        n_off = t.off, n_wtile = t.wtile;
-      }
+      plan_next();
+      stream_next = has_next;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -945,7 +979,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       TileS t;
       t.m0 = n_m0, t.n0 = n_n0, t.y_off = n_yoff, t.b0 = n_b0, t.u00 = n_u00;
       t.off = n_off, t.wtile = n_wtile;
-      setup_tile(t);
+      setup_tile(t, false);
       landed = true;
     } else {
       // (the tap addresses toggle window buffers per pass: back to buffer 0)
@@ -957,8 +991,10 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       // its stores still in flight, the DMAs of the next tile's prologue (every
       // wave is past the last LDS read of the K loop behind this barrier)
       __builtin_amdgcn_s_barrier();
-      const TileS t = tile_of(lin);
-      setup_tile(t);
+      TileS t;
+      t.m0 = n_m0, t.n0 = n_n0, t.y_off = n_yoff, t.b0 = n_b0, t.u00 = n_u00;
+      t.off = n_off, t.wtile = n_wtile;
+      setup_tile(t, true);
       issue_prologue(t);
     }
     CG_TR(7);
