@@ -93,11 +93,15 @@ def test_generated_spike_statistics_match_oracle_trained_model(capsys):
   # the f32 oracle than 1.5x what a second f32 run with other draws is.
   assert d_fr <= 1.5 * alt_fr, (d_fr, emu_fr, alt_fr)
   assert d_cov <= 1.5 * alt_cov, (d_cov, emu_cov, alt_cov)
-  # first moments of the raw generated signals per neuron
+  # first moments of the raw generated signals per neuron.  (Six runs of one
+  # binary: the worst neuron's mean came within 0.011-0.027 and its standard
+  # deviation within 0.001-0.022 of bars of rtol 0.05 / 0.1 + atol 0.02 -- the
+  # path is not run-to-run reproducible (f32 atomics) and 200 train() calls
+  # amplify it --, so the bars carry another 0.02.)
   np.testing.assert_allclose(fake.mean(axis=(0, 1)), gold['f32_fake_mean'],
-                             rtol=0.05, atol=0.02)
+                             rtol=0.05, atol=0.04)
   np.testing.assert_allclose(fake.std(axis=(0, 1)), gold['f32_fake_std'],
-                             rtol=0.1, atol=0.02)
+                             rtol=0.1, atol=0.04)
 
 
 def _trained_maker():
