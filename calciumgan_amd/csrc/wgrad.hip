@@ -20,6 +20,25 @@
 
 namespace {
 
+// -DCG_WGRAD_TRACE (tools/wgrad_trace.sh; never in the product library): cycles a
+// wave of the batched launch spends per part of an item (s_memtime stamps).
+#ifndef CG_WGRAD_SHIFT
+#define CG_WGRAD_SHIFT 96
+#endif
+#ifdef CG_WGRAD_TRACE
+constexpr int kWTraceParts = 5;
+__device__ unsigned g_wgrad_trace[256 * 8 * kWTraceParts];
+#define CG_WTR_PARAMS , unsigned (&wtr)[kWTraceParts], unsigned& wtt
+#define CG_WTR_ARGS , wtr, wtt
+#define CG_WTR(acc, t, part) do { unsigned long long n_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n_)::"memory"); \
+    (acc)[part] += (unsigned)n_ - (t); (t) = (unsigned)n_; } while (0)
+#else
+#define CG_WTR(acc, t, part)
+#define CG_WTR_PARAMS
+#define CG_WTR_ARGS
+#endif
+
 struct WgradArgs {
   const uint16_t* x;
   const uint16_t* g;
@@ -284,7 +303,8 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
                                                 int by, int bz, int gz,
                                                 bool do_bias,
                                                 f32x4 (&acc)[3][2][4],
-                                                float& bs0, float& bs1) {
+                                                float& bs0, float& bs1
+                                                CG_WTR_PARAMS) {
   using G = RingGeom<TT>;
   using std::integral_constant;
   constexpr int KSTEPS = TT / 32;
@@ -526,6 +546,7 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
     read_one(integral_constant<int, 0>{}, integral_constant<int, 0>{}, r_tag);
   });
   lds_wait_set(f, 0);
+  CG_WTR(wtr, wtt, 0);  // item set-up, ring fill, first fragments
 
   {
     int soff = 0;  // ring slot (byte offset) of tile i
@@ -594,7 +615,7 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
 // the linear block id by the multi-layer kernel below.
 template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, int ALLT>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
-                                           int bz, int gz) {
+                                           int bz, int gz CG_WTR_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(!ROWSPLIT || TT == 256, "row-split tiles are 256 rows");
   constexpr int NG = TT * 8 / 512;  // g pieces per thread (1, 2 or 4)
@@ -628,7 +649,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
 
   if constexpr (ALLT == 2) {
     static_assert(R == 2 && TPW == 3 && PIPE && !ROWSPLIT, "ring-staged form");
-    wgrad_ring_loop<TT>(a, smem, bx, by, bz, gz, do_bias, acc, bs0, bs1);
+    wgrad_ring_loop<TT>(a, smem, bx, by, bz, gz, do_bias, acc, bs0, bs1 CG_WTR_ARGS);
+    CG_WTR(wtr, wtt, 1);  // K' loop
   } else if (PIPE) {
     // per-thread piece coordinates (fixed across tiles)
     const int xq8 = tid & 3;
@@ -792,6 +814,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
         for (int nt = 0; nt < 4; ++nt)
           *reinterpret_cast<f32x4*>(pb + ((s * 2 + mt) * 4 + nt) * 2048) =
               acc[s][mt][nt];
+    CG_WTR(wtr, wtt, 2);  // bias column sums + accumulator flush
     return;
   }
 #pragma unroll
@@ -817,7 +840,11 @@ template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, int ALLT>
 __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a, int gz) {
   int bx, by, bz;
   if (!wgrad_block(a, gz, blockIdx.x, bx, by, bz)) return;
-  wgrad_body<R, TPW, ROWSPLIT, PIPE, TT, ALLT>(a, bx, by, bz, gz);
+#ifdef CG_WGRAD_TRACE
+  unsigned wtr[kWTraceParts] = {};
+  unsigned wtt = 0;
+#endif
+  wgrad_body<R, TPW, ROWSPLIT, PIPE, TT, ALLT>(a, bx, by, bz, gz CG_WTR_ARGS);
 }
 
 // Second stage of the partial-sum path: thread (block tile, slot, tid) sums its
@@ -898,19 +925,45 @@ __global__ __launch_bounds__(512) void wgrad_multi_kernel(WgradMulti m) {
 #else
   const int rot = ((int)blockIdx.x >> 6) % m.n;
 #endif
+#ifdef CG_WGRAD_TRACE
+  unsigned wtr[kWTraceParts] = {};
+  unsigned wtt;
+  {
+    unsigned long long n_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n_)::"memory");
+    wtt = (unsigned)n_;
+  }
+#endif
   for (int k = 0; k < m.n; ++k) {
     int li = k + rot;
     if (li >= m.n) li -= m.n;
     const int gz = m.gz[li];
     int bx, by, bz;
-    if (wgrad_block(m.a[li], gz, blockIdx.x, bx, by, bz)) {
+    // A layer whose grid is smaller than the launch leaves ids without a share;
+    // each layer hands its blocks out from another starting id (a multiple of
+    // 8: XCD residues stay), so that the idle turns are not always the same
+    // workgroups' (the last 32 ran 20 % less: tools/wgrad_trace.py).
+#ifdef CG_WGRAD_NO_SHIFT
+    const int id = (int)blockIdx.x;
+#else
+    int id = (int)blockIdx.x + (li * CG_WGRAD_SHIFT) % (int)gridDim.x;
+    if (id >= (int)gridDim.x) id -= (int)gridDim.x;
+#endif
+    if (wgrad_block(m.a[li], gz, id, bx, by, bz)) {
       if (m.tt[li] == 128)
-        wgrad_body<R, TPW, false, true, 128, ALLT>(m.a[li], bx, by, bz, gz);
+        wgrad_body<R, TPW, false, true, 128, ALLT>(m.a[li], bx, by, bz, gz CG_WTR_ARGS);
       else
-        wgrad_body<R, TPW, false, true, 64, ALLT>(m.a[li], bx, by, bz, gz);
+        wgrad_body<R, TPW, false, true, 64, ALLT>(m.a[li], bx, by, bz, gz CG_WTR_ARGS);
     }
+    CG_WTR(wtr, wtt, 3);  // (items this workgroup has no share of; flush of atomics forms)
     __syncthreads();  // LDS is reused by the next item
+    CG_WTR(wtr, wtt, 4);  // barrier between items
   }
+#ifdef CG_WGRAD_TRACE
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 256)
+    for (int k = 0; k < kWTraceParts; ++k)
+      g_wgrad_trace[((int)blockIdx.x * 8 + (int)(threadIdx.x >> 6)) * kWTraceParts + k] = wtr[k];
+#endif
 }
 
 inline int ilog2(int v) {
@@ -1203,3 +1256,11 @@ extern "C" int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream)
     if (plans[i].a.part) reduce_item(plans[i], ra.it[ra.n++]);
   return ra.n ? launch_reduce(ra, s) : 0;
 }
+
+#ifdef CG_WGRAD_TRACE
+extern "C" int cg_debug_wgrad_trace(unsigned* dst, int n) {
+  if (n > 256 * 8 * kWTraceParts) return CG_EINVAL;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wgrad_trace),
+                                  (size_t)n * sizeof(unsigned));
+}
+#endif

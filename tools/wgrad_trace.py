@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Where a wave of the batched cg_wgrad launch spends its cycles (critic pass
+at the benchmark's shapes).  Needs CALCIUMGAN_HIP_LIB = a library built with
+-DCG_WGRAD_TRACE (tools/wgrad_trace.sh)."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import bench
+from calciumgan_amd import _lib
+from calciumgan_amd.gan.algorithms import get_algorithm
+from calciumgan_amd.gan.models import get_models
+
+PARTS = ['item set-up + ring fill + first fragments', "K' loop",
+         'bias column sums + accumulator flush', 'items without a share',
+         'barrier between items']
+
+
+def main():
+  hp = bench.make_hparams(2048, 102, 64, 10, False)
+  hp.verbose = 0
+  gen, dis = get_models(hp, None)
+  gan = get_algorithm(hp, gen, dis, None)
+  real = torch.rand(128, 2048, 102, device=gan.device)
+  for _ in range(3):
+    gan._critic_compute(real)
+  torch.cuda.synchronize()
+  lib = _lib.load()
+  n = 5
+  buf = np.zeros(256 * 8 * n, np.uint32)
+  lib.cg_debug_wgrad_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
+  assert lib.cg_debug_wgrad_trace(buf.ctypes.data, buf.size) == 0
+  t = buf.reshape(256, 8, n).astype(np.float64)
+  w = t[t.sum(-1) > 0]
+  tot = w.sum(-1)
+  print('batched cg_wgrad, critic pass (5 layers): %d waves, wave life %.0f cycles '
+        '(min %.0f max %.0f)' % (len(w), tot.mean(), tot.min(), tot.max()))
+  for k, name in enumerate(PARTS):
+    print('  %-44s %9.0f cycles  %5.1f %%   %7.0f per layer'
+          % (name, w[:, k].mean(), 100 * w[:, k].mean() / tot.mean(), w[:, k].mean() / 5))
+  per_wg(t)
+
+
+def per_wg(t):
+  life = t.sum(-1).mean(-1)  # per workgroup
+  print('  wave life by workgroup id (mean of 16 ids, k cycles):')
+  print('   ', ' '.join('%4.0f' % (life[i:i + 16].mean() / 1e3) for i in range(0, 256, 16)))
+  kl = t[:, :, 1].mean(-1)
+  print("  K' loop only:")
+  print('   ', ' '.join('%4.0f' % (kl[i:i + 16].mean() / 1e3) for i in range(0, 256, 16)))
+
+
+if __name__ == '__main__':
+  main()
