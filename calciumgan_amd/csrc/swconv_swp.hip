@@ -30,7 +30,15 @@
 //     vmcnt two stages later (never in the iteration that issues them);
 //   * weight ring: 3 slots of 64-deep stages.  In the second half of stage s
 //     (after the barrier that publishes stage s+1 and frees slot s) the DMA of
-//     stage s+3 is issued into slot s; it has two whole stages to land.
+//     stage s+3 is issued into slot s; it has two whole stages to land;
+//   * workgroups are persistent (one resident set walks all tiles, XCD residue
+//     kept) and start in four phases a few thousand cycles apart, so that the
+//     two workgroups of a CU are not at a tile boundary together; the epilogue
+//     works in registers (lane swaps, no LDS), its bias comes from an LDS table
+//     filled once per launch, and the next tile's id, scalars and window row
+//     words are worked out between the MFMAs of the running tile's last pass.
+//     Buffer resources stay in SCALAR registers (to_sgpr): built from a
+//     vector-ALU quotient they would wrap every DMA in a waterfall loop.
 #include "swconv_args.h"
 
 namespace {
