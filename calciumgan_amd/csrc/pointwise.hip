@@ -16,6 +16,68 @@ inline unsigned grid1d(long long work, int per_block, long long cap = 1 << 20) {
   return (unsigned)b;
 }
 
+// ---------------------------------------------------------------------------
+// Ordered two-stage reductions (the `ws` argument of the C ABI).  A reducing
+// kernel whose blocks used to meet through f32 atomics -- which land in a
+// different order every run -- instead leaves ONE partial row per block in the
+// caller's workspace, and finish_cols_kernel adds the rows in a fixed order and
+// STORES the result: bit-identical from run to run, no zeroed output needed.
+// Grids are capped at kMaxParts blocks so that the workspace has a fixed size
+// (cg_reduce_ws_elems()).
+// ---------------------------------------------------------------------------
+constexpr int kMaxParts = 2048;
+constexpr long long kReduceWsElems = 4ll << 20;  // 16 MiB of f32
+
+struct FinishArgs {
+  const float* ws;
+  int nparts, ncol;      // partial rows; columns per output
+  long long pstride;     // floats between consecutive partial rows
+  int cstride;           // floats between the outputs' sections inside a row
+  int nout;
+  float* out[3];
+  int cvalid[3];         // columns actually stored per output
+  float scale;
+};
+
+// block = 64 columns x 16 row classes: wave j adds rows j, j + 16, ... (fixed
+// order), the sixteen sums meet through LDS in order 0..15
+__global__ __launch_bounds__(1024) void finish_cols_kernel(FinishArgs f) {
+  __shared__ float sm[16][64];
+  const int lane = threadIdx.x & 63;
+  const int j = threadIdx.x >> 6;
+  const int o = blockIdx.y;
+  const int c = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < f.ncol) {
+    const float* p = f.ws + (long long)o * f.cstride + c;
+    int r = j;
+    for (; r + 48 < f.nparts; r += 64) {
+      const float a0 = p[(long long)r * f.pstride];
+      const float a1 = p[(long long)(r + 16) * f.pstride];
+      const float a2 = p[(long long)(r + 32) * f.pstride];
+      const float a3 = p[(long long)(r + 48) * f.pstride];
+      s += a0;
+      s += a1;
+      s += a2;
+      s += a3;
+    }
+    for (; r < f.nparts; r += 16) s += p[(long long)r * f.pstride];
+  }
+  sm[j][lane] = s;
+  __syncthreads();
+  if (j == 0 && c < f.cvalid[o]) {
+    float t = sm[0][lane];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sm[k][lane];
+    f.out[o][c] = t * f.scale;
+  }
+}
+
+inline void launch_finish(const FinishArgs& f, hipStream_t s) {
+  hipLaunchKernelGGL(finish_cols_kernel, dim3((f.ncol + 63) / 64, f.nout),
+                     dim3(1024), 0, s, f);
+}
+
 __device__ __forceinline__ void unpack8(const uint4 u, float* v) {
   const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -144,24 +206,20 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(
 }
 
 // dy = rstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)), dyh = do * gamma,
-// do = dh * lrelu'(h); dgamma += do * xhat, dbeta += do (per-lane partials ->
-// LDS atomics -> one global atomic per channel per block).
+// do = dh * lrelu'(h); dgamma += do * xhat, dbeta += do: per-lane partials ->
+// a fixed-order sum inside the block -> one partial row per block (ws; summed by
+// finish_cols_kernel) or, without a workspace, one global atomic per channel.
 __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
     const uint16_t* __restrict__ dh, const uint16_t* __restrict__ h,
     const uint16_t* __restrict__ y, const float* __restrict__ mean_i,
     const float* __restrict__ rstd_i, const float* __restrict__ gamma,
     uint16_t* __restrict__ dy, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ dbias, long long rows, int C,
-    int Cp, float alpha, int lpr, int log2lpr, int rows_per_slot) {
-  __shared__ float sg[512];
-  __shared__ float sb[512];
-  __shared__ float sd[512];
-  for (int c = threadIdx.x; c < 512; c += kThreads) {
-    sg[c] = 0.f;
-    sb[c] = 0.f;
-    sd[c] = 0.f;
-  }
-  __syncthreads();
+    int Cp, float alpha, int lpr, int log2lpr, int rows_per_slot,
+    float* __restrict__ ws) {
+  __shared__ float sg[4 * 512];
+  __shared__ float sb[4 * 512];
+  __shared__ float sd[4 * 512];
   const int lane = threadIdx.x & 63;
   const int sub = lane & (lpr - 1);
   const int slot = lane >> log2lpr;
@@ -233,20 +291,42 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
     }
    }
   }
-  if (active) {
+  // rows of the lane slots that share a channel group: xor tree inside the wave
+  // (a fixed order), slot 0 holds the wave's sums
+  for (int o = lpr; o < 64; o <<= 1) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (c0 + e < C) {
-        atomicAdd(&sg[c0 + e], accg[e]);
-        atomicAdd(&sb[c0 + e], accb[e]);
-        if (dbias) atomicAdd(&sd[c0 + e], accd[e]);
-      }
+    for (int e = 0; e < 8; ++e) {
+      accg[e] += __shfl_xor(accg[e], o, 64);
+      accb[e] += __shfl_xor(accb[e], o, 64);
+      accd[e] += __shfl_xor(accd[e], o, 64);
+    }
+  }
+  // the four waves through LDS, added in wave order
+  const int wv = threadIdx.x >> 6;
+  if (slot == 0 && active) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sg[wv * 512 + c0 + e] = accg[e];
+      sb[wv * 512 + c0 + e] = accb[e];
+      sd[wv * 512 + c0 + e] = accd[e];
+    }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += kThreads) {
-    atomicAdd(dgamma + c, sg[c]);
-    atomicAdd(dbeta + c, sb[c]);
-    if (dbias) atomicAdd(dbias + c, sd[c]);
+  for (int c = threadIdx.x; c < Cp; c += kThreads) {
+    const float g4 = ((sg[c] + sg[512 + c]) + sg[1024 + c]) + sg[1536 + c];
+    const float b4 = ((sb[c] + sb[512 + c]) + sb[1024 + c]) + sb[1536 + c];
+    const float d4 = ((sd[c] + sd[512 + c]) + sd[1024 + c]) + sd[1536 + c];
+    if (ws) {
+      // one partial row [3][Cp] per block; finish_cols_kernel adds the rows
+      float* row = ws + (long long)blockIdx.x * 3 * Cp;
+      row[c] = g4;
+      row[Cp + c] = b4;
+      row[2 * Cp + c] = d4;
+    } else if (c < C) {
+      atomicAdd(dgamma + c, g4);
+      atomicAdd(dbeta + c, b4);
+      if (dbias) atomicAdd(dbias + c, d4);
+    }
   }
 }
 

@@ -39,6 +39,8 @@
 //     words are worked out between the MFMAs of the running tile's last pass.
 //     Buffer resources stay in SCALAR registers (to_sgpr): built from a
 //     vector-ALU quotient they would wrap every DMA in a waterfall loop.
+#include <cstdlib>
+
 #include "swconv_args.h"
 
 namespace {
@@ -104,9 +106,25 @@ __device__ __forceinline__ int sw64(int byte) {
   return byte ^ ((byte >> 3) & 32);
 }
 
+// Epilogue forms (template parameter EPI).  The generic one decides everything
+// at run time (epilogue kind, f32 / split-K output, per-sample scale, penalty
+// norm, output-side PhaseShuffle adjoint): ~700 instructions per wave and tile,
+// issued at a quarter of the SIMD's rate while all four waves of the SIMD sit at
+// the same tile boundary (profiles/r03_swp_wave_cycles.txt: 4.8 k of the 8.5 k
+// boundary cycles).  The lean forms cover what the cfg2 step launches most,
+// with everything else compiled out, wave-uniform row addressing on the scalar
+// ALU (one 64-bit base per wave, 32-bit lane offsets, buffer stores) and no
+// integer division:
+//   kEpiLrelu      bias + max(v, alpha v) (alpha = 1: plain), bf16 rows
+//   kEpiMask       bias, optional per-sample scale, LeakyReLU' mask (in place
+//                  or not), bf16 rows
+//   kEpiMaskShift  the same with the output-side PhaseShuffle adjoint
+//                  (cg_conv_desc.out_shifts): rows land at their source positions
+constexpr int kEpiGeneric = 0, kEpiLrelu = 1, kEpiMask = 2, kEpiMaskShift = 3;
+
 // R: source stride.  WM x WN waves (4 or 8); wave tile (16 * MT) x 64.
 // LN: CG_EPI_LN_LRELU (LayerNorm + LeakyReLU in the epilogue; 128-column tiles).
-template <int R, int WM, int WN, int MT, bool LN, bool NRW>
+template <int R, int WM, int WN, int MT, bool LN, bool NRW, int EPI>
 __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   static_assert(WM * WN == 4 || WM * WN == 8, "one or two waves per SIMD");
   static_assert(!NRW || R == 2, "narrow last chunks exist for stride 2 only");
@@ -237,7 +255,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     return t;
   };
   // per-tile state of the K loop
-  int m0 = 0, n0 = 0, y_off = 0, b0 = 0;
+  int m0 = 0, n0 = 0, y_off = 0, b0 = 0, u00 = 0;
   CG_TR_DECL;
   // source rows of this lane's window pieces, packed: bits [0, 14) the row of
   // source-row parity 0, [14, 28) of parity 1 (kRowPad = zero padding), [28, 31)
@@ -343,6 +361,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     n0 = t.n0;
     y_off = t.y_off;
     b0 = t.b0;
+    u00 = t.u00;
     if (!words_done)
       static_for<KPW>([&](auto k_tag) { store_word(k_tag, t.b0, t.u00, t.off); });
     rx = x_rsrc(t.b0);
@@ -923,6 +942,207 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     }
   };
 
+  // ---- lean epilogues (EPI != kEpiGeneric; see the list above the template) -----
+  // A wave's 16 MT rows lie in one sample (S >= 16 MT), so sample, first row and
+  // the PhaseShuffle shift are wave-uniform: the row base is ONE 64-bit scalar
+  // address per wave (shifts of the tile's own sample / row, no division), a lane
+  // adds a 32-bit offset, and out-of-range lanes are switched off by an offset
+  // past num_records (the buffer form of the store drops them).
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  // (lane offset of a switched-off lane: past num_records whatever the scalar
+  // offset adds, and no 32-bit wrap)
+  constexpr int kOff = (int)0x80000000u;
+  auto rsrc_at = [&](const void* p0, long long byte_off) {
+    const unsigned long long p = reinterpret_cast<unsigned long long>(p0) +
+                                 (unsigned long long)byte_off;
+    const unsigned lo = (unsigned)to_sgpr((int)(unsigned)p);
+    const unsigned hi = (unsigned)to_sgpr((int)(unsigned)(p >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff,
+        0x00020000);
+  };
+  auto epilogue_lean = [&](int en0, int ey_off, int eb0, int eu00) {
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(acc[mt][nt]));
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int rM = lane & 15;
+    const int g = lane >> 4;
+    const int cq = (g & 1) * 16 + (g >> 1) * 8;  // lane's column inside a block pair
+    en0 = to_sgpr(en0);
+    const int nl0 = en0 + wn * 64 + cq;          // lane's first column of block pair 0
+    const int i0 = wm * MT * 16;                 // first tile row of this wave
+    const int bw = to_sgpr(eb0) + (i0 >> a.log2S);
+    if (bw >= a.nB) return;                      // rows past M: the whole wave
+    const int uw0 = (a.nseg > 1 ? 0 : to_sgpr(eu00)) + (i0 & (a.S - 1));
+    // position of the wave's first row inside its sample, in output rows
+    const int t0 = a.y_stride * uw0 + to_sgpr(ey_off);
+    const int rowB = a.Cy * 2;                   // bytes per output row
+    const int mt_step = 16 * a.y_stride * rowB;  // bytes between the two subtiles
+    const bool cols_open = en0 + TN > a.Cy;      // the column tile overhangs the pitch
+    const bool zero_tail = en0 + TN > a.N;       // ... or the real channels
+    float bv[2][8];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f32x4 b0v = *reinterpret_cast<const f32x4*>(bias_lds + nl0 + p * 32);
+      const f32x4 b1v = *reinterpret_cast<const f32x4*>(bias_lds + nl0 + p * 32 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bv[p][e] = b0v[e];
+        bv[p][4 + e] = b1v[e];
+      }
+    }
+    auto finish8 = [&](float (&v)[8], int n) {
+      if (zero_tail) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e >= a.N) v[e] = 0.f;
+      }
+      return u32x4{pack2act(v[0], v[1]), pack2act(v[2], v[3]), pack2act(v[4], v[5]),
+                   pack2act(v[6], v[7])};
+    };
+    auto masked8 = [&](float (&v)[8], const u32x4 h4, bool round_first) {
+      const uint32_t hw[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (round_first) v[e] = act2f(f2act(v[e]));
+        const uint16_t hv = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
+        v[e] *= (act2f(hv) > 0.f) ? 1.f : a.alpha;
+      }
+    };
+    if constexpr (EPI == kEpiLrelu || EPI == kEpiMask) {
+      const long long base = (((long long)bw * a.Ly + t0) * a.Cy) * 2;
+      const __amdgpu_buffer_rsrc_t ry = rsrc_at(a.y, base);
+      const int voff = rM * a.y_stride * rowB + nl0 * 2;
+      int vo[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        vo[p] = (cols_open && nl0 + p * 32 >= a.Cy) ? kOff : voff + p * 64;
+      u32x4 mk[MT][2];
+      float rs = 1.f;
+      if constexpr (EPI == kEpiMask) {
+        const __amdgpu_buffer_rsrc_t rm = rsrc_at(a.mask, base);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            mk[mt][p] = __builtin_amdgcn_raw_buffer_load_b128(rm, vo[p], mt * mt_step, 0);
+        if (a.row_scale) rs = a.row_scale[bw];
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          float v[8];
+          pair8(mt, p, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bv[p][e];
+          if constexpr (EPI == kEpiLrelu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], a.alpha * v[e]);
+          } else {
+            if (a.row_scale) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= rs;
+            }
+            masked8(v, mk[mt][p], false);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(finish8(v, nl0 + p * 32), ry, vo[p],
+                                                 mt * mt_step, 0);
+        }
+    } else {
+      // kEpiMaskShift: row t of the sample lands on t + shift; the |shift| rows
+      // that the reflection folds back go, unmasked, to the side buffer
+      // (cg_unshuffle_fixup adds them in)
+      int oshift = a.out_shifts[bw / a.out_seg];
+      const int tlast = t0 + a.y_stride * (16 * MT - 1);
+      const bool any_side = oshift > 0 ? tlast >= a.Ly - oshift : t0 < -oshift;
+      if (!any_side) {
+        const long long base = (((long long)bw * a.Ly + t0 + oshift) * a.Cy) * 2;
+        const __amdgpu_buffer_rsrc_t ry = rsrc_at(a.y, base);
+        const __amdgpu_buffer_rsrc_t rm = rsrc_at(a.mask, base);
+        const int voff = rM * a.y_stride * rowB + nl0 * 2;
+        int vo[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          vo[p] = (cols_open && nl0 + p * 32 >= a.Cy) ? kOff : voff + p * 64;
+        u32x4 mk[MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            mk[mt][p] = __builtin_amdgcn_raw_buffer_load_b128(rm, vo[p], mt * mt_step, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            float v[8];
+            pair8(mt, p, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[p][e];
+            masked8(v, mk[mt][p], true);
+            __builtin_amdgcn_raw_buffer_store_b128(finish8(v, nl0 + p * 32), ry, vo[p],
+                                                   mt * mt_step, 0);
+          }
+      } else {
+        // the one or two waves per sample whose rows reach the reflected end:
+        // per-lane targets, one store instruction per destination buffer
+        const __amdgpu_buffer_rsrc_t ry =
+            rsrc_at(a.y, ((long long)bw * a.Ly * a.Cy) * 2);
+        const __amdgpu_buffer_rsrc_t rm =
+            rsrc_at(a.mask, ((long long)bw * a.Ly * a.Cy) * 2);
+        const __amdgpu_buffer_rsrc_t rsd =
+            rsrc_at(a.side, ((long long)bw * a.side_rows * a.Cy) * 2);
+        int vy[MT][2], vs[MT][2];
+        u32x4 mk[MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          int t = t0 + a.y_stride * (mt * 16 + rM);
+          bool to_side;
+          if (oshift > 0) {
+            to_side = t >= a.Ly - oshift;
+            t = to_side ? t - (a.Ly - oshift) : t + oshift;
+          } else {
+            to_side = t < -oshift;
+            t = to_side ? t : t + oshift;
+          }
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const bool ok = !(cols_open && nl0 + p * 32 >= a.Cy);
+            const int o = t * rowB + (nl0 + p * 32) * 2;
+            vy[mt][p] = (ok && !to_side) ? o : kOff;
+            vs[mt][p] = (ok && to_side) ? o : kOff;
+            mk[mt][p] = __builtin_amdgcn_raw_buffer_load_b128(rm, vy[mt][p], 0, 0);
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            float v[8], vm[8];
+            pair8(mt, p, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[e] += bv[p][e];
+              vm[e] = v[e];
+            }
+            masked8(vm, mk[mt][p], true);
+            __builtin_amdgcn_raw_buffer_store_b128(finish8(vm, nl0 + p * 32), ry,
+                                                   vy[mt][p], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(finish8(v, nl0 + p * 32), rsd,
+                                                   vs[mt][p], 0, 0);
+          }
+      }
+    }
+  };
+
   // ---- the tile loop -----------------------------------------------------------
   lin = next_tile((int)blockIdx.x);
   if (lin >= pa.ntl) return;
@@ -976,8 +1196,9 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     CG_TR(6);  // prologue barrier + first fragment reads
     for (int p = 0; p < full_passes; ++p) run_pass(False{}, p);
     if constexpr (NRW) run_pass(True{}, full_passes);
-    const int em0 = m0, en0 = n0, ey_off = y_off, eb0 = b0;
-    epilogue(em0, en0, ey_off, eb0);
+    const int em0 = m0, en0 = n0, ey_off = y_off, eb0 = b0, eu00 = u00;
+    if constexpr (EPI == kEpiGeneric || LN) epilogue(em0, en0, ey_off, eb0);
+    else epilogue_lean(en0, ey_off, eb0, eu00);
     CG_TR(8);  // epilogue
     lin = lin_next;
     if (lin >= pa.ntl) break;
@@ -1019,15 +1240,16 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
 // directly in a __global__ template the host pass emits no stub for it)
 // (second launch bound = waves per SIMD the register budget must allow: the
 // 32-row wave tiles run 3 four-wave or 2 eight-wave workgroups per CU)
-template <int R, int WM, int WN, int MT, bool LN = false, bool NRW = false>
+template <int R, int WM, int WN, int MT, bool LN = false, bool NRW = false,
+          int EPI = kEpiGeneric>
 __global__ __launch_bounds__(WM* WN * 64, MT == 2 ? (WM * WN == 8 ? 4 : 3) : 2) void
 swconv_swp_kernel(SwpArgs pa) {
-  swconv_swp_body<R, WM, WN, MT, LN, NRW>(pa);
+  swconv_swp_body<R, WM, WN, MT, LN, NRW, EPI>(pa);
 }
 
 // Workgroups of one instantiation a CU holds at `lds` bytes of dynamic LDS
 // (registers, LDS and the wave slots together; asked of the runtime once).
-template <int R, int WM, int WN, int MT, bool LN, bool NRW>
+template <int R, int WM, int WN, int MT, bool LN, bool NRW, int EPI>
 int swp_occupancy(size_t lds) {
   static size_t known_lds = 0;
   static int known = 0;
@@ -1035,7 +1257,8 @@ int swp_occupancy(size_t lds) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
             &nb,
-            reinterpret_cast<const void*>(&swconv_swp_kernel<R, WM, WN, MT, LN, NRW>),
+            reinterpret_cast<const void*>(
+                &swconv_swp_kernel<R, WM, WN, MT, LN, NRW, EPI>),
             WM * WN * 64, lds) != hipSuccess || nb < 1)
       nb = 1;
     known = nb;
@@ -1058,13 +1281,15 @@ inline int swp_num_cus() {
   return cus;
 }
 
-template <int R, int WM, int WN, int MT, bool LN = false, bool NRW = false>
+template <int R, int WM, int WN, int MT, bool LN = false, bool NRW = false,
+          int EPI = kEpiGeneric>
 int launch_swp(const SwpArgs& pa, unsigned gy, size_t lds, bool dry, hipStream_t s) {
   if (dry) return 0;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&swconv_swp_kernel<R, WM, WN, MT, LN, NRW>),
+        reinterpret_cast<const void*>(
+            &swconv_swp_kernel<R, WM, WN, MT, LN, NRW, EPI>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -1072,13 +1297,14 @@ int launch_swp(const SwpArgs& pa, unsigned gy, size_t lds, bool dry, hipStream_t
   // persistent workgroups: one resident set walks all tiles (a multiple of 8
   // workgroups, so each keeps its XCD residue over its tiles)
   long long slots =
-      (long long)swp_num_cus() * swp_occupancy<R, WM, WN, MT, LN, NRW>(lds);
+      (long long)swp_num_cus() * swp_occupancy<R, WM, WN, MT, LN, NRW, EPI>(lds);
   slots = slots / 8 * 8;
   if (gy > 1) slots = (slots / gy) / 8 * 8;  // the split-K slices share the CUs
   if (slots < 8) slots = 8;
   const unsigned gx = (unsigned)(pa.ntl < slots ? pa.ntl : slots);
-  CG_LAUNCH_PROF(CG_FAMILY_SWCONV, (swconv_swp_kernel<R, WM, WN, MT, LN, NRW>),
-                 dim3(gx, gy), dim3(WM * WN * 64), lds, s, pa);
+  CG_LAUNCH_PROF(CG_FAMILY_SWCONV,
+                 (swconv_swp_kernel<R, WM, WN, MT, LN, NRW, EPI>), dim3(gx, gy),
+                 dim3(WM * WN * 64), lds, s, pa);
   CG_LAUNCH_CHECK();
 }
 
@@ -1091,6 +1317,13 @@ extern "C" int cg_debug_swp_trace(unsigned* dst, int n) {
                                   (size_t)n * sizeof(unsigned));
 }
 #endif
+
+// CALCIUMGAN_SWP_GENERIC_EPI=1: every launch takes the run-time epilogue (A/B of
+// the lean forms inside one library; read once)
+static const bool g_swp_generic_epi = [] {
+  const char* e = getenv("CALCIUMGAN_SWP_GENERIC_EPI");
+  return e && e[0] == '1';
+}();
 
 int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
                       int ksplit, bool dry, hipStream_t stream) {
@@ -1149,11 +1382,35 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
     if (wm == 4 && mt == 2) return launch_swp<1, 4, 2, 2, true>(pa, grid, lds, dry, stream);
     return CG_EINVAL;
   }
-#define CG_SWP(RR, WM, WN, MM, NN)                                          \
-  if (stride == RR && wm == WM && wn == WN && mt == MM && narrow == NN)     \
-    return launch_swp<RR, WM, WN, MM, false, NN != 0>(pa, grid, lds, dry, stream);
+  // lean epilogue forms: the 32-row wave tiles (what the tuner picks for nearly
+  // every cfg2 geometry), bf16 rows, no split-K / f32 output / penalty norm
+  int epi = kEpiGeneric;
+  if (mt == 2 && !a.out_f32 && !a.rowsumsq && ksplit <= 1 && !g_swp_generic_epi) {
+    if ((a.epilogue == CG_EPI_NONE || a.epilogue == CG_EPI_LRELU) &&
+        !a.out_shifts && !a.row_scale) {
+      epi = kEpiLrelu;
+      if (a.epilogue == CG_EPI_NONE) pa.c.alpha = 1.f;  // max(v, v)
+    } else if (a.epilogue == CG_EPI_MASK && !a.out_shifts) {
+      epi = kEpiMask;
+    } else if (a.epilogue == CG_EPI_MASK && !a.row_scale && stride == 1) {
+      epi = kEpiMaskShift;
+    }
+    // (stride 1 carries the two forms its launches use, stride 2 likewise)
+    if (stride == 1 && epi == kEpiMask) epi = kEpiGeneric;
+  }
+#define CG_SWP_E(RR, WM, WN, MM, NN, EE)                                     \
+  if (stride == RR && wm == WM && wn == WN && mt == MM && narrow == NN &&    \
+      epi == EE)                                                             \
+    return launch_swp<RR, WM, WN, MM, false, NN != 0, EE>(pa, grid, lds, dry, \
+                                                           stream);
+#define CG_SWP(RR, WM, WN, MM, NN) CG_SWP_E(RR, WM, WN, MM, NN, kEpiGeneric)
 #define CG_SWP_R(WM, WN, MM) \
   CG_SWP(1, WM, WN, MM, 0) CG_SWP(2, WM, WN, MM, 0) CG_SWP(2, WM, WN, MM, 1)
+#define CG_SWP_LEAN(WM, WN, MM)                                              \
+  CG_SWP_E(1, WM, WN, MM, 0, kEpiLrelu) CG_SWP_E(1, WM, WN, MM, 0, kEpiMaskShift) \
+  CG_SWP_E(2, WM, WN, MM, 0, kEpiLrelu) CG_SWP_E(2, WM, WN, MM, 0, kEpiMask)  \
+  CG_SWP_E(2, WM, WN, MM, 1, kEpiLrelu) CG_SWP_E(2, WM, WN, MM, 1, kEpiMask)
+  CG_SWP_LEAN(4, 1, 2) CG_SWP_LEAN(8, 1, 2) CG_SWP_LEAN(4, 2, 2)
   CG_SWP_R(8, 1, 4)   // 512 x 64, 8 waves
   CG_SWP_R(4, 1, 4)   // 256 x 64, 4 waves
   CG_SWP_R(4, 2, 4)   // 256 x 128, 8 waves
@@ -1161,7 +1418,9 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   CG_SWP_R(4, 1, 2)   // 128 x 64, 4 waves
   CG_SWP_R(8, 1, 2)   // 256 x 64, 8 waves
   CG_SWP_R(4, 2, 2)   // 128 x 128, 8 waves
+#undef CG_SWP_LEAN
 #undef CG_SWP_R
 #undef CG_SWP
+#undef CG_SWP_E
   return CG_EINVAL;
 }
