@@ -64,6 +64,7 @@ class ConvDesc(C.Structure):
       ('side_rows', c_i),
       ('ksplit', c_i), ('split_ws', c_vp), ('split_ws_elems', c_ll),
       ('row_scale', c_vp),
+      ('rowsumsq_ws', c_vp), ('rowsumsq_ws_elems', c_ll),
   ]
 
 
@@ -95,6 +96,7 @@ class WgradDesc(C.Structure):
       ('bias_rows', c_ll),
       ('partials', c_vp),
       ('partials_elems', c_ll),
+      ('store', c_i),
   ]
 
 
@@ -108,6 +110,8 @@ SIGNATURES = {
     'cg_profile_collect': [C.POINTER(c_f), C.POINTER(c_i), c_i],
     'cg_swconv': [C.POINTER(ConvDesc), c_vp],
     'cg_swconv_check': [C.POINTER(ConvDesc)],
+    'cg_rowsumsq_ws_elems': [C.POINTER(ConvDesc)],
+    'cg_reduce_ws_elems': [],
     'cg_dense_rows': [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_vp],
     'cg_dense_rows_act': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],
     'cg_dense_wgrad': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_vp, c_ll,
@@ -124,12 +128,12 @@ SIGNATURES = {
     'cg_ln_lrelu_fwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_f,
                         c_f, c_vp],
     'cg_ln_lrelu_bwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                        c_vp, c_ll, c_i, c_i, c_f, c_vp],
+                        c_vp, c_ll, c_i, c_i, c_f, c_vp, c_vp],
     'cg_dense1_fwd': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     'cg_dense1_bwd': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f,
                       c_vp],
     'cg_dense1_wgrad': [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i,
-                        c_vp],
+                        c_vp, c_vp],
     'cg_unshuffle_mask': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_f,
                           c_vp],
     'cg_unshuffle_fixup': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f,
@@ -137,12 +141,12 @@ SIGNATURES = {
     'cg_interp_pack': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_vp],
     'cg_cast_pad': [c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],
-    'cg_rownorm': [c_vp, c_vp, c_i, c_ll, c_vp],
+    'cg_rownorm': [c_vp, c_vp, c_i, c_ll, c_vp, c_vp],
     'cg_gp_finalize': [c_vp, c_vp, c_vp, c_i, c_f, c_i, c_vp],
     'cg_scale_rows': [c_vp, c_vp, c_vp, c_i, c_ll, c_vp],
     'cg_critic_loss': [c_vp, c_vp, c_f, c_vp, c_i, c_vp],
     'cg_neg_mean': [c_vp, c_vp, c_i, c_vp],
-    'cg_colsum': [c_vp, c_vp, c_ll, c_i, c_i, c_vp],
+    'cg_colsum': [c_vp, c_vp, c_ll, c_i, c_i, c_vp, c_vp],
     'cg_sigmoid_bwd': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],
     'cg_lrelu_bwd': [c_vp, c_vp, c_vp, c_ll, c_f, c_vp],
     'cg_adam': [c_vp, c_vp, c_vp, c_vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_vp,
@@ -152,11 +156,13 @@ SIGNATURES = {
                        c_vp, c_vp],
     'cg_loss_scale_update': [c_vp, c_i, c_vp],
     'cg_signal_metrics': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_f, c_f,
-                          c_vp],
+                          c_vp, c_vp],
+    'cg_step_outputs': [c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_vp],
 }
 _RESTYPES = {'cg_packed_elems': c_ll, 'cg_pack_plan_bytes': c_ll,
              'cg_pack_plan_build': c_ll, 'cg_wgrad_partials_elems': c_ll,
-             'cg_dense_wgrad_ws_elems': c_ll}
+             'cg_dense_wgrad_ws_elems': c_ll, 'cg_rowsumsq_ws_elems': c_ll,
+             'cg_reduce_ws_elems': c_ll}
 
 _libs = {}       # precision -> ctypes handle
 _active = 'bf16'  # precision of the library `call` / `load()` address

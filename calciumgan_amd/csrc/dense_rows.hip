@@ -482,23 +482,42 @@ __global__ __launch_bounds__(kDwThreads, 2) void dense_wgrad_kernel(
       }
 }
 
-// dW[e] += sum over the row ranges of their partial tiles (few output tiles:
-// a thousand workgroups adding into the same 10 K addresses serialise -- 150 us
-// of atomics at cfg2 against 30 us of streaming)
-__global__ void dense_wgrad_reduce_kernel(const float* __restrict__ part,
-                                          float* __restrict__ dw, long long n,
-                                          int nsplit) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  // blockIdx.y sums its share of the row ranges (a lone thread walking all of
-  // them is 512 dependent-latency loads: 100 us), one atomic per share
-  const int per = (nsplit + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int k0 = (int)blockIdx.y * per;
-  const int k1 = k0 + per < nsplit ? k0 + per : nsplit;
+// dW[e] = sum over the row ranges of their partial tiles, in a fixed order (few
+// output tiles: a thousand workgroups adding into the same 10 K addresses
+// serialise -- 150 us of atomics at cfg2 against 30 us of streaming).  Block =
+// 64 elements x 16 shares: share j adds ranges j, j + 16, ... (a lone thread
+// walking all of them is 512 dependent-latency loads: 100 us), the sixteen sums
+// meet through LDS in share order; the result is STORED.
+__global__ __launch_bounds__(1024) void dense_wgrad_reduce_kernel(
+    const float* __restrict__ part, float* __restrict__ dw, long long n,
+    int nsplit) {
+  __shared__ float sm[16][64];
+  const int lane = threadIdx.x & 63;
+  const int j = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + lane;
   float s = 0.f;
-#pragma unroll 8
-  for (int k = k0; k < k1; ++k) s += part[(long long)k * n + i];
-  if (k1 > k0) atomicAdd(dw + i, s);
+  if (i < n) {
+    int k = j;
+    for (; k + 48 < nsplit; k += 64) {
+      const float a0 = part[(long long)k * n + i];
+      const float a1 = part[(long long)(k + 16) * n + i];
+      const float a2 = part[(long long)(k + 32) * n + i];
+      const float a3 = part[(long long)(k + 48) * n + i];
+      s += a0;
+      s += a1;
+      s += a2;
+      s += a3;
+    }
+    for (; k < nsplit; k += 16) s += part[(long long)k * n + i];
+  }
+  sm[j][lane] = s;
+  __syncthreads();
+  if (j == 0 && i < n) {
+    float t = sm[0][lane];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sm[k][lane];
+    dw[i] = t;
+  }
 }
 
 }  // namespace
@@ -569,16 +588,16 @@ extern "C" long long cg_dense_wgrad_ws_elems(long long rows, int Cx_real,
                                              int Cg_real) {
   if (rows < 1 || Cx_real < 1 || Cg_real < 1) return -1;
   const int ntiles = ((Cx_real + 127) / 128) * ((Cg_real + 127) / 128);
-  if (ntiles > 4) return 0;  // many tiles: atomics, no workspace
   long long nsplit, rps;
   dense_wgrad_split(rows, ntiles, nsplit, rps);
   return nsplit * (long long)Cx_real * Cg_real;
 }
 
-// dW[cx][cg] += sum_r x[r][cx] * g[r][cg]  (f32 [Cx_real][Cg_real], row-major;
-// the caller zeroes dW): the weight gradient of the per-timestep Dense.  `ws`
-// (cg_dense_wgrad_ws_elems floats, or null): partial tiles + a reducing launch
-// instead of atomics.
+// The weight gradient of the per-timestep Dense.  ws == NULL:
+// dW[cx][cg] += sum_r x[r][cx] * g[r][cg] by f32 atomics (f32 [Cx_real][Cg_real],
+// row-major; the caller zeroes dW).  With `ws` (cg_dense_wgrad_ws_elems floats):
+// partial tiles + a reducing launch that adds them in a fixed order and STORES
+// dW (no zeroed buffer, the same bits every run).
 extern "C" int cg_dense_wgrad(const void* x, const void* g, float* dw,
                               long long rows, int Cx, int Cg, int Cx_real,
                               int Cg_real, float* ws, long long ws_elems,
@@ -601,13 +620,13 @@ extern "C" int cg_dense_wgrad(const void* x, const void* g, float* dw,
   dense_wgrad_split(rows, ntiles, nsplit, rps);
   a.rows_per_split = rps;
   const long long n = (long long)Cx_real * Cg_real;
-  a.part = (ws && ntiles <= 4 && ws_elems >= nsplit * n) ? ws : nullptr;
+  if (ws && ws_elems < nsplit * n) return CG_EINVAL;
+  a.part = ws;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(dense_wgrad_kernel, dim3((unsigned)(nsplit * ntiles)),
                      dim3(kDwThreads), 0, s, a);
   if (a.part)
-    hipLaunchKernelGGL(dense_wgrad_reduce_kernel,
-                       dim3((unsigned)((n + 255) / 256), 32), dim3(256), 0, s,
-                       a.part, dw, n, (int)nsplit);
+    hipLaunchKernelGGL(dense_wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)),
+                       dim3(1024), 0, s, a.part, dw, n, (int)nsplit);
   CG_LAUNCH_CHECK();
 }

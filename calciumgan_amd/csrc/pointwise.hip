@@ -391,11 +391,14 @@ __global__ __launch_bounds__(kThreads) void dense1_bwd_kernel(
   store8(delta + (long long)b * F + i, o);
 }
 
-// dw[i] += sum_b coef[seg(b)] * x[b][i]; grid (F/8/256, bsplit)
+// dw[i] += sum_b coef[seg(b)] * x[b][i]; grid (F/8/256, bsplit).  With a
+// workspace the sample splits leave partial rows ws[split][Fpad] (+ their share of
+// the bias sum behind them) and dense1_wgrad_finish adds them in split order.
 __global__ __launch_bounds__(kThreads) void dense1_wgrad_kernel(
     const uint16_t* __restrict__ x, const float* __restrict__ coef,
     const float* __restrict__ bias_coef, float* __restrict__ dw,
-    float* __restrict__ db, int nB, int F, int C, int Cp, int seg_size) {
+    float* __restrict__ db, int nB, int F, int C, int Cp, int seg_size,
+    float* __restrict__ ws, int Fpad) {
   const int i = (blockIdx.x * kThreads + threadIdx.x) * 8;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float bsum = 0.f;
@@ -420,6 +423,15 @@ __global__ __launch_bounds__(kThreads) void dense1_wgrad_kernel(
       for (int e = 0; e < 8; ++e) acc[e] += cf[k] * v[e];
     }
   }
+  if (ws) {
+    float* row = ws + (long long)blockIdx.y * Fpad;
+    if (i < F) {
+      *reinterpret_cast<f32x4*>(row + i) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<f32x4*>(row + i + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    }
+    if (i == 0) ws[(long long)gridDim.y * Fpad + blockIdx.y] = bsum;
+    return;
+  }
   // transpose through LDS so that one atomic instruction covers 64 consecutive
   // features (256 contiguous bytes) instead of 64 features 32 bytes apart
   __shared__ float tr[kThreads * 8];
@@ -438,6 +450,25 @@ __global__ __launch_bounds__(kThreads) void dense1_wgrad_kernel(
     }
   }
   if (i == 0 && db && bias_coef) atomicAdd(db, bsum);
+}
+
+// dw[t * C + ch] = sum over the splits, in split order (one thread per feature)
+__global__ __launch_bounds__(kThreads) void dense1_wgrad_finish(
+    const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db,
+    int nsplit, int F, int Fpad, int C, int Cp, int has_bias) {
+  const int f = blockIdx.x * kThreads + threadIdx.x;
+  if (f < F) {
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += ws[(long long)z * Fpad + f];
+    const int t = f / Cp;
+    const int ch = f - t * Cp;
+    if (ch < C) dw[t * C + ch] = s;
+  }
+  if (f == 0 && db && has_bias) {
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += ws[(long long)nsplit * Fpad + z];
+    db[0] = s;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -490,6 +521,8 @@ __global__ __launch_bounds__(kThreads) void unshuffle_mask_kernel(
 // Second half of the unshuffle fused into the producing convolution
 // (cg_conv_desc.out_shifts): thread (b, j, 8 channels), j < |s|, zeroes the
 // row nothing maps to and folds reflected row j into its source row.
+// (One launch per layer: the next input-gradient launch of the chain reads the
+// rows this one completes, so the layers of a pass cannot share a launch.)
 __global__ __launch_bounds__(kThreads) void unshuffle_fixup_kernel(
     const uint16_t* __restrict__ side, const uint16_t* __restrict__ h,
     uint16_t* __restrict__ delta, const int* __restrict__ shifts, int w, int Cp,
@@ -561,9 +594,11 @@ __global__ __launch_bounds__(kThreads) void cast_pad_kernel(
   store8(dst + row * Cp + c, v);
 }
 
-// sumsq[b] += partial of g bf16 [B][n]; grid (chunks, B)
+// sumsq[b] += partial of g bf16 [B][n]; grid (chunks, B).  With a workspace the
+// chunks leave ws[b][chunk] and sqrt_sum_kernel adds them in chunk order.
 __global__ __launch_bounds__(kThreads) void sumsq_kernel(
-    const uint16_t* __restrict__ g, float* __restrict__ sumsq, long long n) {
+    const uint16_t* __restrict__ g, float* __restrict__ sumsq, long long n,
+    float* __restrict__ ws) {
   __shared__ float part[4];
   const int b = blockIdx.y;
   const uint16_t* p = g + (long long)b * n;
@@ -578,8 +613,20 @@ __global__ __launch_bounds__(kThreads) void sumsq_kernel(
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0)
-    atomicAdd(sumsq + b, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) {
+    const float t = ((part[0] + part[1]) + part[2]) + part[3];
+    if (ws) ws[(long long)b * gridDim.x + blockIdx.x] = t;
+    else atomicAdd(sumsq + b, t);
+  }
+}
+
+__global__ void sqrt_sum_kernel(const float* __restrict__ ws, float* v, int n,
+                                int chunks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += ws[(long long)i * chunks + c];
+  v[i] = sqrtf(s);
 }
 
 // (a kernel, not hipMemsetAsync: inside the captured step that call is a memset
@@ -669,18 +716,17 @@ __global__ void neg_mean_kernel(const float* __restrict__ d_out,
 }
 
 // column sums: block handles `rows_per_block` rows of one slab of up to 2048
-// channels (blockIdx.y); thread -> (8-channel group, row lane); LDS reduce then
-// one atomic per channel per block.
+// channels (blockIdx.y); thread -> (8-channel group, row lane); the row lanes
+// meet through LDS in a fixed order, then one partial row per block (ws, summed
+// by finish_cols_kernel) or one atomic per channel per block.
 __global__ __launch_bounds__(kThreads) void colsum_kernel(
     const uint16_t* __restrict__ x, float* __restrict__ out, long long rows,
-    int C, int Cp, int rows_per_block) {
-  extern __shared__ float sacc[];  // [slab channels]
+    int C, int Cp, int rows_per_block, float* __restrict__ ws) {
+  __shared__ float sacc[kThreads * 8];  // [row lane][slab channel]
   const int c_base = blockIdx.y * (kThreads * 8);
   const int slab = min(Cp - c_base, kThreads * 8);
   const int groups = slab / 8;
   const int rlanes = kThreads / groups;  // rows processed concurrently
-  for (int c = threadIdx.x; c < slab; c += kThreads) sacc[c] = 0.f;
-  __syncthreads();
   const int grp = threadIdx.x % groups;
   const int rl = threadIdx.x / groups;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -706,11 +752,15 @@ __global__ __launch_bounds__(kThreads) void colsum_kernel(
       }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(&sacc[grp * 8 + e], acc[e]);
+    for (int e = 0; e < 8; ++e) sacc[rl * slab + grp * 8 + e] = acc[e];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < slab; c += kThreads)
-    if (c_base + c < C) atomicAdd(out + c_base + c, sacc[c]);
+  for (int c = threadIdx.x; c < slab; c += kThreads) {
+    float t = sacc[c];
+    for (int r = 1; r < rlanes; ++r) t += sacc[r * slab + c];
+    if (ws) ws[(long long)blockIdx.x * Cp + c_base + c] = t;
+    else if (c_base + c < C) atomicAdd(out + c_base + c, t);
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void sigmoid_bwd_kernel(
@@ -820,7 +870,8 @@ __global__ void loss_scale_update_kernel(float* __restrict__ ls, float interval)
 __global__ __launch_bounds__(kThreads) void signal_metrics_kernel(
     const float* __restrict__ real, const float* __restrict__ fake,
     float* __restrict__ out, long long rows, int C, int Cr, int Cf, float smin,
-    float scale, int lpr, int log2lpr, int rows_per_slot) {
+    float scale, int lpr, int log2lpr, int rows_per_slot,
+    float* __restrict__ ws) {
   __shared__ float part[4][4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -945,9 +996,30 @@ __global__ __launch_bounds__(kThreads) void signal_metrics_kernel(
   if (lane == 0)
     for (int k = 0; k < 4; ++k) part[wave][k] = acc[k];
   __syncthreads();
-  if (threadIdx.x < 4)
-    atomicAdd(out + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] +
-                                     part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (threadIdx.x < 4) {
+    const float t = ((part[0][threadIdx.x] + part[1][threadIdx.x]) +
+                     part[2][threadIdx.x]) + part[3][threadIdx.x];
+    if (ws) ws[(long long)blockIdx.x * 4 + threadIdx.x] = t;
+    else atomicAdd(out + threadIdx.x, t);
+  }
+}
+
+// the seven scalars train() returns, in one launch: [gen_loss, mean critic loss,
+// mean penalty, metrics x 4] (wgan_gp.py:82-95 averages the critic's values over
+// its n_critic updates)
+__global__ void step_outputs_kernel(const float* __restrict__ gen_loss,
+                                    const float* __restrict__ loss,
+                                    const float* __restrict__ gp,
+                                    const float* __restrict__ metrics, int n,
+                                    float* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i == 0) out[0] = gen_loss[0];
+  if (i == 1 || i == 2) {
+    float s = 0.f;
+    for (int k = 0; k < n; ++k) s += (i == 1) ? loss[2 * k] : gp[k];
+    out[i] = n > 0 ? s / n : 0.f;
+  }
+  if (i >= 3 && i < 7) out[i] = metrics[i - 3];
 }
 
 inline int rows_per_slot_for(long long rows, int rpw, int lo, int hi) {
@@ -982,23 +1054,42 @@ extern "C" int cg_ln_lrelu_fwd(const void* y_pre, const float* gamma,
   CG_LAUNCH_CHECK();
 }
 
+extern "C" long long cg_reduce_ws_elems(void) { return kReduceWsElems; }
+
 extern "C" int cg_ln_lrelu_bwd(const void* dh, const void* h, const void* y_pre,
                                const float* mean, const float* rstd,
                                const float* gamma, void* dy, float* dgamma,
                                float* dbeta, float* dbias, long long rows,
-                               int C, int Cp, float alpha, void* stream) {
+                               int C, int Cp, float alpha, float* ws,
+                               void* stream) {
   if (Cp % 8 || Cp > 512 || C > Cp || rows < 1) return CG_EINVAL;
   int lpr = 1, l2 = 0;
   while (lpr * 8 < Cp) { lpr <<= 1; ++l2; }
   const int rpw = 64 / lpr;
-  // (longer runs than the forward: every block ends with 3*C global atomics
-  // onto the same addresses, which serialise -- fewer, longer blocks)
-  const int rows_per_slot = rows_per_slot_for(rows, rpw, 16, 64);
-  hipLaunchKernelGGL(ln_bwd_kernel,
-                     dim3(grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31)),
-                     dim3(kThreads), 0, S_(stream), U16(dh), U16(h), U16(y_pre),
-                     mean, rstd, gamma, U16W(dy), dgamma, dbeta, dbias, rows, C,
-                     Cp, alpha, lpr, l2, rows_per_slot);
+  // atomics: long runs (every block ends with 3*C global atomics onto the same
+  // addresses, which serialise -- fewer, longer blocks); partial rows: a block
+  // ends with one coalesced store, so shorter runs and more blocks in flight,
+  // capped at kMaxParts blocks (the workspace's size)
+  int rows_per_slot = ws ? rows_per_slot_for(rows, rpw, 4, 16)
+                         : rows_per_slot_for(rows, rpw, 16, 64);
+  if (ws) {
+    while ((rows + 4ll * rpw * rows_per_slot - 1) / (4ll * rpw * rows_per_slot) >
+           kMaxParts)
+      rows_per_slot *= 2;
+  }
+  const unsigned blocks = grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(kThreads), 0, S_(stream),
+                     U16(dh), U16(h), U16(y_pre), mean, rstd, gamma, U16W(dy),
+                     dgamma, dbeta, dbias, rows, C, Cp, alpha, lpr, l2,
+                     rows_per_slot, ws);
+  if (ws) {
+    FinishArgs f;
+    f.ws = ws; f.nparts = (int)blocks; f.ncol = Cp; f.pstride = 3ll * Cp;
+    f.cstride = Cp; f.nout = dbias ? 3 : 2; f.scale = 1.f;
+    f.out[0] = dgamma; f.out[1] = dbeta; f.out[2] = dbias;
+    f.cvalid[0] = f.cvalid[1] = f.cvalid[2] = C;
+    launch_finish(f, S_(stream));
+  }
   CG_LAUNCH_CHECK();
 }
 
@@ -1027,16 +1118,22 @@ extern "C" int cg_dense1_bwd(const float* w, const float* coef, const void* h,
 extern "C" int cg_dense1_wgrad(const void* x, const float* coef,
                                const float* bias_coef, float* dw, float* db,
                                int nB, int Lt, int C, int Cp, int seg_size,
-                               void* stream) {
+                               float* ws, void* stream) {
   const int F = Lt * Cp;
   if (Cp % 8 || C > Cp || nB < 1 || seg_size < 1) return CG_EINVAL;
   const int gx = (F / 8 + kThreads - 1) / kThreads;
   int gy = 512 / gx;
   if (gy < 1) gy = 1;
   if (gy > nB) gy = nB;
+  const int Fpad = gx * kThreads * 8;
+  if (ws && (long long)gy * Fpad + gy > kReduceWsElems) return CG_EINVAL;
   hipLaunchKernelGGL(dense1_wgrad_kernel, dim3(gx, gy), dim3(kThreads), 0,
                      S_(stream), U16(x), coef, bias_coef, dw, db, nB, F, C,
-                     Cp, seg_size);
+                     Cp, seg_size, ws, Fpad);
+  if (ws)
+    hipLaunchKernelGGL(dense1_wgrad_finish, dim3((F + kThreads - 1) / kThreads),
+                       dim3(kThreads), 0, S_(stream), ws, dw, db, gy, F, Fpad, C,
+                       Cp, bias_coef ? 1 : 0);
   CG_LAUNCH_CHECK();
 }
 
@@ -1091,14 +1188,22 @@ extern "C" int cg_cast_pad(const float* src, void* dst, long long rows, int C,
 }
 
 extern "C" int cg_rownorm(const void* g, float* norm, int B, long long n,
-                          void* stream) {
+                          float* ws, void* stream) {
   if (n % 8 || B < 1) return CG_EINVAL;
-  hipLaunchKernelGGL(zero_f32_kernel, dim3((B + 255) / 256), dim3(256), 0,
-                     S_(stream), norm, B);
   int chunks = (int)((n / 8 + kThreads - 1) / kThreads);
   if (chunks > 64) chunks = 64;
+  if (ws) {
+    if ((long long)B * chunks > kReduceWsElems) return CG_EINVAL;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(chunks, B), dim3(kThreads), 0,
+                       S_(stream), U16(g), norm, n, ws);
+    hipLaunchKernelGGL(sqrt_sum_kernel, dim3((B + 255) / 256), dim3(256), 0,
+                       S_(stream), ws, norm, B, chunks);
+    CG_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((B + 255) / 256), dim3(256), 0,
+                     S_(stream), norm, B);
   hipLaunchKernelGGL(sumsq_kernel, dim3(chunks, B), dim3(kThreads), 0,
-                     S_(stream), U16(g), norm, n);
+                     S_(stream), U16(g), norm, n, (float*)nullptr);
   hipLaunchKernelGGL(sqrt_kernel, dim3((B + 255) / 256), dim3(256), 0,
                      S_(stream), norm, B);
   CG_LAUNCH_CHECK();
@@ -1135,19 +1240,31 @@ extern "C" int cg_neg_mean(const float* d_out, float* out, int B, void* stream) 
 }
 
 extern "C" int cg_colsum(const void* x, float* out, long long rows, int C,
-                         int Cp, void* stream) {
+                         int Cp, float* ws, void* stream) {
   if (Cp % 8 || C > Cp || rows < 1) return CG_EINVAL;
-  // enough rows per block to amortise the LDS/global atomics, still >= ~512
-  // blocks on the large activations
+  // enough rows per block to amortise the block's closing reduction, still
+  // >= ~512 blocks on the large activations
   int rows_per_block = 256;
   while (rows_per_block < 4096 && rows / (rows_per_block * 2) >= 512)
     rows_per_block *= 2;
+  if (ws) {
+    // partial rows [block][Cp] must fit the workspace
+    while ((rows + rows_per_block - 1) / rows_per_block > kMaxParts ||
+           ((rows + rows_per_block - 1) / rows_per_block) * Cp > kReduceWsElems)
+      rows_per_block *= 2;
+  }
   const int slabs = (Cp + kThreads * 8 - 1) / (kThreads * 8);
-  const int slab_ch = Cp < kThreads * 8 ? Cp : kThreads * 8;
-  hipLaunchKernelGGL(colsum_kernel,
-                     dim3(grid1d(rows, rows_per_block, 1LL << 31), slabs),
-                     dim3(kThreads), slab_ch * sizeof(float), S_(stream), U16(x),
-                     out, rows, C, Cp, rows_per_block);
+  const unsigned blocks = grid1d(rows, rows_per_block, 1LL << 31);
+  hipLaunchKernelGGL(colsum_kernel, dim3(blocks, slabs), dim3(kThreads), 0,
+                     S_(stream), U16(x), out, rows, C, Cp, rows_per_block, ws);
+  if (ws) {
+    FinishArgs f;
+    f.ws = ws; f.nparts = (int)blocks; f.ncol = Cp; f.pstride = Cp;
+    f.cstride = 0; f.nout = 1; f.scale = 1.f;
+    f.out[0] = out; f.out[1] = f.out[2] = nullptr;
+    f.cvalid[0] = C; f.cvalid[1] = f.cvalid[2] = 0;
+    launch_finish(f, S_(stream));
+  }
   CG_LAUNCH_CHECK();
 }
 
@@ -1213,19 +1330,42 @@ extern "C" int cg_loss_scale_update(float* ls, int growth_interval,
 
 extern "C" int cg_signal_metrics(const float* real, const float* fake,
                                  float* out, long long rows, int C, int Cr,
-                                 int Cf, float smin, float smax, void* stream) {
+                                 int Cf, float smin, float smax, float* ws,
+                                 void* stream) {
   if (rows < 1 || C < 1 || Cr < C || Cf < C) return CG_EINVAL;
   int lpr = 1, l2 = 0;
   while (lpr * 8 < C && lpr < 64) { lpr <<= 1; ++l2; }
   const int rpw = 64 / lpr;
-  // every block ends with 4 atomics on the same 4 addresses, which serialise:
-  // ~1024 blocks on the large inputs
+  // every block ends with 4 atomics on the same 4 addresses, which serialise
+  // (or one partial row of 4 floats): ~1024 blocks on the large inputs
   int rows_per_slot = 4;
   while (rows_per_slot < 64 && rows / ((long long)4 * rpw * rows_per_slot) > 1024)
     rows_per_slot *= 2;
-  hipLaunchKernelGGL(signal_metrics_kernel,
-                     dim3(grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31)),
-                     dim3(kThreads), 0, S_(stream), real, fake, out, rows, C,
-                     Cr, Cf, smin, smax - smin, lpr, l2, rows_per_slot);
+  if (ws) {
+    while ((rows + 4ll * rpw * rows_per_slot - 1) / (4ll * rpw * rows_per_slot) >
+           kMaxParts)
+      rows_per_slot *= 2;
+  }
+  const unsigned blocks = grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31);
+  hipLaunchKernelGGL(signal_metrics_kernel, dim3(blocks), dim3(kThreads), 0,
+                     S_(stream), real, fake, out, rows, C, Cr, Cf, smin,
+                     smax - smin, lpr, l2, rows_per_slot, ws);
+  if (ws) {
+    FinishArgs f;
+    f.ws = ws; f.nparts = (int)blocks; f.ncol = 4; f.pstride = 4;
+    f.cstride = 0; f.nout = 1; f.scale = 1.f / (float)rows;  // the means
+    f.out[0] = out; f.out[1] = f.out[2] = nullptr;
+    f.cvalid[0] = 4; f.cvalid[1] = f.cvalid[2] = 0;
+    launch_finish(f, S_(stream));
+  }
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_step_outputs(const float* gen_loss, const float* loss,
+                               const float* gp, const float* metrics, int n,
+                               float* out, void* stream) {
+  if (!gen_loss || !loss || !gp || !metrics || !out || n < 0) return CG_EINVAL;
+  hipLaunchKernelGGL(step_outputs_kernel, dim3(1), dim3(64), 0, S_(stream),
+                     gen_loss, loss, gp, metrics, n, out);
   CG_LAUNCH_CHECK();
 }

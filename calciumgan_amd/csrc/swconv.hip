@@ -661,9 +661,28 @@ swconv_kernel(ConvArgs a) {
     float* wsum = reinterpret_cast<float*>(smem) + kScratchBytes / 4;
     if (lane == 0) wsum[wave] = ssq;
     __syncthreads();
-    if (tid == 0 && m0 < a.M)
-      atomicAdd(a.rowsumsq + m0 / a.Lu, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+    if (tid == 0 && m0 < a.M) {
+      const float t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+      const int b = m0 / a.Lu;
+      if (a.ssq_ws) {
+        const int rt = (m0 - b * a.Lu) / TM;
+        a.ssq_ws[(long long)b * a.ssq_P + (rt * a.gp + phase) * a.gn + bn] = t;
+      } else {
+        atomicAdd(a.rowsumsq + b, t);
+      }
+    }
   }
+}
+
+// second half of the ordered penalty norm: rowsumsq[b] = the sample's slots
+// added in slot order
+__global__ void rowsumsq_finish_kernel(const float* __restrict__ ws, int P,
+                                       float* __restrict__ out, int nB) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nB) return;
+  float s = 0.f;
+  for (int j = 0; j < P; ++j) s += ws[(long long)b * P + j];
+  out[b] = s;
 }
 
 // Split-K finishing pass (cg_conv_desc.ksplit): one thread per 8 output
@@ -1195,6 +1214,22 @@ static int swconv_run(const cg_conv_desc* d, void* stream) {
   a.w_phase_stride = d->w_phase_stride;
   a.off_phase_step = d->off_phase_step;
   a.yoff_phase_step = d->yoff_phase_step;
+  // ordered penalty norm: one slot per (row tile of the sample, phase, column
+  // tile); the finishing launch below adds a sample's slots in order
+  a.ssq_ws = nullptr;
+  a.ssq_P = 0;
+  if (d->rowsumsq && d->rowsumsq_ws) {
+    a.ssq_P = (d->Lu / TM) * d->nphase * ((d->N + TN - 1) / TN);
+    if (d->rowsumsq_ws_elems < (long long)d->nB * a.ssq_P) return CG_EINVAL;
+    a.ssq_ws = d->rowsumsq_ws;
+  }
+  auto ssq_finish = [&](int rc) {
+    if (rc || !a.ssq_ws || g_dry_run) return rc;
+    hipLaunchKernelGGL(rowsumsq_finish_kernel, dim3((d->nB + 255) / 256), dim3(256),
+                       0, (hipStream_t)stream, a.ssq_ws, a.ssq_P, d->rowsumsq,
+                       d->nB);
+    return (int)hipGetLastError();
+  };
   if (tc.swp_wm) {
     // software-pipelined tile: its own LDS plan and launch (swconv_swp.hip;
     // inherently one parity at a time: split_parity is not consulted)
@@ -1204,7 +1239,7 @@ static int swconv_run(const cg_conv_desc* d, void* stream) {
     a.gp = d->nphase;
     const int rc = swconv_swp_launch(a, R, tc.swp_wm, tc.wgn, tc.mt, a.ksplit,
                                      g_dry_run, (hipStream_t)stream);
-    if (rc || a.ksplit == 1 || g_dry_run) return rc;
+    if (rc || a.ksplit == 1 || g_dry_run) return ssq_finish(rc);
     // (both launches carry their own event pair under cg_profile_enable)
     return split_finish_launch(d, a, (hipStream_t)stream, true, nullptr);
   }
@@ -1252,6 +1287,17 @@ static int swconv_run(const cg_conv_desc* d, void* stream) {
 #undef CG_DISPATCH_RK
 #undef CG_DISPATCH
   g_split_prof.on = false;
-  if (rc || a.ksplit == 1 || g_dry_run) return rc;
+  if (rc || a.ksplit == 1 || g_dry_run) return ssq_finish(rc);
   return split_finish_launch(d, a, s, false, split_timed ? split_stop : nullptr);
+}
+
+extern "C" long long cg_rowsumsq_ws_elems(const cg_conv_desc* d) {
+  if (!d || d->tile < 0 || d->tile >= CG_NUM_TILES || d->Lu < 1 || d->nB < 1)
+    return -1;
+  if (!d->rowsumsq) return 0;
+  const TileCfg tc = kTileCfgs[d->tile];
+  const int TM = tc.swp_wm ? tc.swp_wm * tc.mt * 16 : (4 / tc.wgn) * tc.mt * tc.mf;
+  const int TN = 64 * tc.wgn;
+  if (d->Lu % TM) return -1;  // (rowsumsq needs one sample per tile)
+  return (long long)d->nB * (d->Lu / TM) * d->nphase * ((d->N + TN - 1) / TN);
 }

@@ -42,6 +42,11 @@ struct ConvArgs {
   uint16_t* side;
   int side_rows;
   const float* row_scale;  // per-sample scale in front of the epilogue, or null
+  // ordered penalty norm (cg_conv_desc.rowsumsq_ws): slot
+  // ((row tile in the sample) * gp + phase) * gn + column tile of sample b's
+  // ssq_P slots receives the workgroup's sum with a plain store
+  float* ssq_ws;
+  int ssq_P;
 };
 
 // swconv_swp.hip: launch (or, dry, only validate) a software-pipelined tile of

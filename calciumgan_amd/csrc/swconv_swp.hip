@@ -235,6 +235,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   struct TileS {
     int m0, n0, y_off, b0, u00, off;
     int wtile;  // byte offset of the tile's (phase, first column) in the operand
+    int ss;     // the tile's slot of the ordered penalty norm (a.ssq_ws)
   };
   auto tile_of = [&](int lin) {
     TileS t;
@@ -252,10 +253,11 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     t.u00 = t.m0 - t.b0 * a.Lu;       // its first output row (nseg == 1)
     t.wtile = (int)(((long long)phase * a.w_phase_stride +
                      (long long)t.n0 * a.Kpack) * 2);
+    t.ss = ((t.u00 / TM) * a.gp + phase) * a.gn + bn;
     return t;
   };
   // per-tile state of the K loop
-  int m0 = 0, n0 = 0, y_off = 0, b0 = 0, u00 = 0;
+  int m0 = 0, n0 = 0, y_off = 0, b0 = 0, u00 = 0, sslot = 0;
   CG_TR_DECL;
   // source rows of this lane's window pieces, packed: bits [0, 14) the row of
   // source-row parity 0, [14, 28) of parity 1 (kRowPad = zero padding), [28, 31)
@@ -362,6 +364,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     y_off = t.y_off;
     b0 = t.b0;
     u00 = t.u00;
+    sslot = t.ss;
     if (!words_done)
       static_for<KPW>([&](auto k_tag) { store_word(k_tag, t.b0, t.u00, t.off); });
     rx = x_rsrc(t.b0);
@@ -558,6 +561,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   // the lambdas' references they went through private memory and came back as
   // per-lane values -- a waterfall loop around every DMA)
   int n_m0 = 0, n_n0 = 0, n_yoff = 0, n_b0 = 0, n_u00 = 0, n_off = 0, n_wtile = 0;
+  int n_ss = 0;
   bool stream_next = false;
   // The running tile, the one after it and whether there is one.  Kernels that
   // keep the tile boundary work the next tile out INSIDE the last pass of the
@@ -574,7 +578,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     if (has_next) {
       const TileS t = tile_of(lin_next);
       n_m0 = t.m0, n_n0 = t.n0, n_yoff = t.y_off, n_b0 = t.b0, n_u00 = t.u00;
-      n_off = t.off, n_wtile = t.wtile;
+      n_off = t.off, n_wtile = t.wtile, n_ss = t.ss;
     }
   };
   auto run_pass = [&](auto narrow_tag, int p) {
@@ -706,7 +710,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       v[4 + r] = __uint_as_float(sw[1]);
     }
   };
-  auto epilogue = [&](int em0, int en0, int ey_off, int eb0) {
+  auto epilogue = [&](int em0, int en0, int ey_off, int eb0, int ess) {
     // the matrix pipe retires the last MFMAs (inline assembly: the compiler's
     // hazard recognizer does not see them) before ordinary instructions read acc
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -936,7 +940,10 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
         if (tid == 0 && em0 < a.M) {
           float t = 0.f;
           for (int w = 0; w < NW; ++w) t += wsum[w];
-          atomicAdd(a.rowsumsq + eb0, t);
+          // (ordered form: the workgroup's own slot, summed by the finishing
+          // launch; else one f32 atomic per workgroup)
+          if (a.ssq_ws) a.ssq_ws[(long long)eb0 * a.ssq_P + ess] = t;
+          else atomicAdd(a.rowsumsq + eb0, t);
         }
       }
     }
@@ -961,7 +968,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
         reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff,
         0x00020000);
   };
-  auto epilogue_lean = [&](int en0, int ey_off, int eb0, int eu00) {
+  auto epilogue_lean = [&](int en0, int ey_off, int eb0, int eu00, int ess) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -999,11 +1006,20 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
         bv[p][4 + e] = b1v[e];
       }
     }
+    // (kEpiLrelu also carries the penalty norm: the f32 sum of squares of what
+    // the wave stores, before rounding -- the x^ input gradient's launch)
+    float ssq = 0.f;
     auto finish8 = [&](float (&v)[8], int n) {
       if (zero_tail) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (n + e >= a.N) v[e] = 0.f;
+      }
+      if constexpr (EPI == kEpiLrelu) {
+        if (a.rowsumsq) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
+        }
       }
       return u32x4{pack2act(v[0], v[1]), pack2act(v[2], v[3]), pack2act(v[4], v[5]),
                    pack2act(v[6], v[7])};
@@ -1016,6 +1032,19 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
         const uint16_t hv = (uint16_t)(hw[e >> 1] >> ((e & 1) * 16));
         v[e] *= (act2f(hv) > 0.f) ? 1.f : a.alpha;
       }
+    };
+    // Subtile mt of a lane: + mt * mt_step bytes, added on the VECTOR side.  (As
+    // the scalar offset of the store it corrupted data: with a register in the
+    // soffset field hipcc assumes that a 16-byte store has read its data registers
+    // at issue and lets the next instructions overwrite them -- the third store of
+    // this epilogue was followed by writes to its data registers two instructions
+    // later, and under back-pressure the last lanes the store reads, rows 12-15
+    // of a 16-row block, saw the new values: about one element in 10^4 at the
+    // benchmark's shapes, none in the small kernel tests.  With soffset 0 the
+    // compiler keeps its wait states; tests/test_hip_fullsize.py holds the case.)
+    auto store_rows = [&](const u32x4 d, __amdgpu_buffer_rsrc_t r, int vofs, int mt) {
+      const int o = vofs == kOff ? kOff : vofs + mt * mt_step;
+      __builtin_amdgcn_raw_buffer_store_b128(d, r, o, 0, 0);
     };
     if constexpr (EPI == kEpiLrelu || EPI == kEpiMask) {
       const long long base = (((long long)bw * a.Ly + t0) * a.Cy) * 2;
@@ -1054,9 +1083,24 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
             }
             masked8(v, mk[mt][p], false);
           }
-          __builtin_amdgcn_raw_buffer_store_b128(finish8(v, nl0 + p * 32), ry, vo[p],
-                                                 mt * mt_step, 0);
+          store_rows(finish8(v, nl0 + p * 32), ry, vo[p], mt);
         }
+      if constexpr (EPI == kEpiLrelu) {
+        if (a.rowsumsq) {
+          // the whole tile belongs to one sample (nseg == 1, checked on the
+          // host; every wave of the workgroup is here): the workgroup's own slot
+          // of the ordered sum, or one f32 atomic
+          ssq = wave_sum(ssq);
+          if (lane == 0) wsum[wave] = ssq;
+          __syncthreads();
+          if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < NW; ++w) t += wsum[w];
+            if (a.ssq_ws) a.ssq_ws[(long long)bw * a.ssq_P + to_sgpr(ess)] = t;
+            else atomicAdd(a.rowsumsq + bw, t);
+          }
+        }
+      }
     } else {
       // kEpiMaskShift: row t of the sample lands on t + shift; the |shift| rows
       // that the reflection folds back go, unmasked, to the side buffer
@@ -1088,8 +1132,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += bv[p][e];
             masked8(v, mk[mt][p], true);
-            __builtin_amdgcn_raw_buffer_store_b128(finish8(v, nl0 + p * 32), ry, vo[p],
-                                                   mt * mt_step, 0);
+            store_rows(finish8(v, nl0 + p * 32), ry, vo[p], mt);
           }
       } else {
         // the one or two waves per sample whose rows reach the reflected end:
@@ -1197,8 +1240,8 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     for (int p = 0; p < full_passes; ++p) run_pass(False{}, p);
     if constexpr (NRW) run_pass(True{}, full_passes);
     const int em0 = m0, en0 = n0, ey_off = y_off, eb0 = b0, eu00 = u00;
-    if constexpr (EPI == kEpiGeneric || LN) epilogue(em0, en0, ey_off, eb0);
-    else epilogue_lean(en0, ey_off, eb0, eu00);
+    if constexpr (EPI == kEpiGeneric || LN) epilogue(em0, en0, ey_off, eb0, sslot);
+    else epilogue_lean(en0, ey_off, eb0, eu00, sslot);
     CG_TR(8);  // epilogue
     lin = lin_next;
     if (lin >= pa.ntl) break;
@@ -1207,7 +1250,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       // (published by the last stage boundary of the pass just run)
       TileS t;
       t.m0 = n_m0, t.n0 = n_n0, t.y_off = n_yoff, t.b0 = n_b0, t.u00 = n_u00;
-      t.off = n_off, t.wtile = n_wtile;
+      t.off = n_off, t.wtile = n_wtile, t.ss = n_ss;
       setup_tile(t, false);
       landed = true;
     } else {
@@ -1222,7 +1265,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
       __builtin_amdgcn_s_barrier();
       TileS t;
       t.m0 = n_m0, t.n0 = n_n0, t.y_off = n_yoff, t.b0 = n_b0, t.u00 = n_u00;
-      t.off = n_off, t.wtile = n_wtile;
+      t.off = n_off, t.wtile = n_wtile, t.ss = n_ss;
       setup_tile(t, true);
       issue_prologue(t);
     }
@@ -1385,11 +1428,13 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   // lean epilogue forms: the 32-row wave tiles (what the tuner picks for nearly
   // every cfg2 geometry), bf16 rows, no split-K / f32 output / penalty norm
   int epi = kEpiGeneric;
-  if (mt == 2 && !a.out_f32 && !a.rowsumsq && ksplit <= 1 && !g_swp_generic_epi) {
+  if (mt == 2 && !a.out_f32 && ksplit <= 1 && !g_swp_generic_epi) {
     if ((a.epilogue == CG_EPI_NONE || a.epilogue == CG_EPI_LRELU) &&
         !a.out_shifts && !a.row_scale) {
-      epi = kEpiLrelu;
+      epi = kEpiLrelu;  // (with or without the penalty norm)
       if (a.epilogue == CG_EPI_NONE) pa.c.alpha = 1.f;  // max(v, v)
+    } else if (a.rowsumsq) {
+      epi = kEpiGeneric;
     } else if (a.epilogue == CG_EPI_MASK && !a.out_shifts) {
       epi = kEpiMask;
     } else if (a.epilogue == CG_EPI_MASK && !a.row_scale && stride == 1) {

@@ -55,6 +55,12 @@ struct WgradArgs {
   // K'-split partial sums as plain stores (reduced by wgrad_reduce_kernel)
   // instead of f32 atomics into dw; null: atomics
   float* part;
+  // ... and the splits' bias column sums [gz][gy][64] (behind the dw partials in
+  // the caller's workspace; added in split order by wgrad_reduce_kernel)
+  float* bias_part;
+  // a launch with ONE K' split owns every dw / dbias element once: stored
+  // directly when the caller asked for `store` (else added, onto zeros)
+  int direct_store;
   int pgx, pgy;  // (cx, cg) block grid of the launch
   // XCD-grouped block order (speed only): the gsz workgroups that stream the
   // same x and / or g tiles of one K' split get linear ids that differ by 8
@@ -788,17 +794,26 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
     }
   }
   if (do_bias) {
-    // 16 row groups -> one value per channel through LDS, then one global
-    // atomic per channel per workgroup
+    // 16 row groups -> one value per channel through LDS, added in row-group
+    // order; then the workgroup's own slot of the bias partials (summed over the
+    // K' splits by the reducing launch) or one global atomic per channel
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
-    if (tid < 64) red[tid] = 0.f;
-    __syncthreads();
     const int cp = (tid & 31) * 2;
-    atomicAdd(&red[cp], bs0);
-    atomicAdd(&red[cp + 1], bs1);
+    red[(tid >> 5) * 64 + cp] = bs0;
+    red[(tid >> 5) * 64 + cp + 1] = bs1;
     __syncthreads();
-    if (tid < 64 && cg0 + tid < a.Cg_real) atomicAdd(a.dbias + cg0 + tid, red[tid]);
+    if (tid < 64) {
+      float t = red[tid];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) t += red[k * 64 + tid];
+      if (a.bias_part)
+        a.bias_part[((long long)bz * a.pgy + by) * 64 + tid] = t;
+      else if (cg0 + tid < a.Cg_real) {
+        if (a.direct_store) a.dbias[cg0 + tid] = t;
+        else atomicAdd(a.dbias + cg0 + tid, t);
+      }
+    }
   }
 
   if (!ROWSPLIT && a.part) {
@@ -817,6 +832,38 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
     CG_WTR(wtr, wtt, 2);  // bias column sums + accumulator flush
     return;
   }
+  if constexpr (ROWSPLIT) {
+    // the eight waves hold partial sums of the SAME dw tile (they split the
+    // rows): added through LDS in wave order, one adder per element
+    static_assert(TPW == 1, "row-split tiles have one tap");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [8 waves][32 regs][64 lanes]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          red[(wave * 32 + (mt * 4 + nt) * 4 + r) * 64 + lane] = acc[0][mt][nt][r];
+    __syncthreads();
+    // thread (wave, lane) finishes registers wave * 4 .. wave * 4 + 3
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int reg = wave * 4 + q4;
+      float t = red[reg * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) t += red[(w * 32 + reg) * 64 + lane];
+      const int mt = reg >> 4, nt = (reg >> 2) & 3, r = reg & 3;
+      const int cx = cx0 + mt * 16 + 4 * g4 + r;
+      const int cg = cg0 + nt * 16 + r16;
+      if (cx < a.Cx_real && cg < a.Cg_real) {
+        float* q = a.dw + (long long)cx * a.Cg_real + cg;
+        if (a.direct_store) *q = t;
+        else atomicAdd(q, t);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < TPW; ++s) {
     const int tap = ROWSPLIT ? 0 : wave + 8 * s;
@@ -829,9 +876,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
         for (int r = 0; r < 4; ++r) {
           const int cx = cx0 + mt * 16 + 4 * g4 + r;
           const int cg = cg0 + nt * 16 + r16;
-          if (cx < a.Cx_real && cg < a.Cg_real)
-            atomicAdd(a.dw + ((long long)tap * a.Cx_real + cx) * a.Cg_real + cg,
-                      acc[s][mt][nt][r]);
+          if (cx < a.Cx_real && cg < a.Cg_real) {
+            float* q = a.dw + ((long long)tap * a.Cx_real + cx) * a.Cg_real + cg;
+            if (a.direct_store) *q = acc[s][mt][nt][r];
+            else atomicAdd(q, acc[s][mt][nt][r]);
+          }
         }
   }
 }
@@ -854,6 +903,9 @@ struct ReduceItem {
   const float* part;
   float* dw;
   int gx, gy, gz, tpw, taps, Cx_real, Cg_real;
+  int store;               // dw / dbias are stored, not added to
+  const float* bias_part;  // [gz][gy][64] or null
+  float* dbias;
 };
 struct ReduceArgs {
   int n;
@@ -862,6 +914,17 @@ struct ReduceArgs {
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceArgs ra) {
   const ReduceItem& it = ra.it[blockIdx.y];
+  if (it.bias_part && blockIdx.x == 0) {
+    // conv bias gradient: the K' splits' column sums, in split order
+    for (int c = threadIdx.x; c < it.gy * 64; c += 256) {
+      float s = 0.f;
+      for (int z = 0; z < it.gz; ++z) s += it.bias_part[(long long)z * it.gy * 64 + c];
+      if (c < it.Cg_real) {
+        if (it.store) it.dbias[c] = s;
+        else it.dbias[c] += s;
+      }
+    }
+  }
   const int per_tile = it.tpw * 8 * 512;  // float4 per block tile
   const long long total = (long long)it.gx * it.gy * per_tile;
   const long long blk_stride = (long long)it.gx * it.gy * per_tile * 4;  // floats per split
@@ -892,8 +955,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceArgs ra) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int cx = bx * 32 + mt * 16 + 4 * (lane >> 4) + r;
-        if (cx < it.Cx_real)
-          it.dw[((long long)tap * it.Cx_real + cx) * it.Cg_real + cg] += sum[r];
+        if (cx < it.Cx_real) {
+          float* q = it.dw + ((long long)tap * it.Cx_real + cx) * it.Cg_real + cg;
+          *q = it.store ? sum[r] : *q + sum[r];
+        }
       }
     }
   }
@@ -1031,7 +1096,8 @@ namespace {
 struct WgradPlan {
   WgradArgs a;
   int gx, gy, nsplit, TT, R, tpw;
-  long long part_elems;
+  long long part_elems, bias_elems;
+  int store;
   size_t lds, ring_lds;
   bool pipe, rowsplit;
 };
@@ -1127,12 +1193,23 @@ int plan_wgrad(const cg_wgrad_desc* d, WgradPlan& p) {
     }
     if (d->no_xcd_group) { a.gmode = 3; a.gsz = 1; }
   }
-  p.part_elems = (rowsplit || nsplit < 2)
-                     ? 0
-                     : (long long)p.gx * p.gy * nsplit * p.tpw * 8 * 2048;
+  const long long dw_part = (rowsplit || nsplit < 2)
+                                ? 0
+                                : (long long)p.gx * p.gy * nsplit * p.tpw * 8 * 2048;
+  p.bias_elems = (dw_part && d->dbias) ? (long long)nsplit * p.gy * 64 : 0;
+  p.part_elems = dw_part + p.bias_elems;
+  a.bias_part = nullptr;
+  a.direct_store = 0;
+  p.store = 0;
   if (d->partials && p.part_elems > 0) {
     if (d->partials_elems < p.part_elems) return CG_EINVAL;
     a.part = d->partials;
+    if (p.bias_elems) a.bias_part = d->partials + dw_part;
+    p.store = d->store ? 1 : 0;
+  } else if (d->store) {
+    // stores need a single owner per element: one K' split
+    if (nsplit != 1) return CG_EINVAL;
+    a.direct_store = 1;
   }
   return 0;
 }
@@ -1141,6 +1218,7 @@ void reduce_item(const WgradPlan& p, ReduceItem& it) {
   it.part = p.a.part; it.dw = p.a.dw;
   it.gx = p.gx; it.gy = p.gy; it.gz = p.nsplit; it.tpw = p.tpw;
   it.taps = p.a.taps; it.Cx_real = p.a.Cx_real; it.Cg_real = p.a.Cg_real;
+  it.store = p.store; it.bias_part = p.a.bias_part; it.dbias = p.a.dbias;
 }
 
 int launch_reduce(const ReduceArgs& ra, hipStream_t s) {

@@ -58,11 +58,17 @@ class GAN(object):
     fake_pitch (defaults to C)."""
     B, L, C = real.shape
     rows = B * L
-    buf = torch.zeros(4, dtype=torch.float32, device=self.device)
+    rws = nets.reduce_ws(self.device)
+    if rws is not None:
+      # ordered reduction: the finishing launch stores the means
+      buf = torch.empty(4, dtype=torch.float32, device=self.device)
+    else:
+      buf = torch.zeros(4, dtype=torch.float32, device=self.device)
     _lib.call('cg_signal_metrics', nets._p(real), nets._p(fake), nets._p(buf),
               rows, C, C, fake_pitch or C, self._signals_min,
-              self._signals_max, nets._stream())
-    buf.mul_(1.0 / rows)
+              self._signals_max, nets._p(rws), nets._stream())
+    if rws is None:
+      buf.mul_(1.0 / rows)
     return {
         'signals_metrics/min': buf[0],
         'signals_metrics/max': buf[1],

@@ -160,7 +160,8 @@ class WGAN_GP(GAN):
     else:
       norm = st['norm']
       squared = 0
-      _lib.call('cg_rownorm', nets._p(plan.gin), nets._p(norm), B, n, s)
+      _lib.call('cg_rownorm', nets._p(plan.gin), nets._p(norm), B, n,
+                nets._p(nets.reduce_ws(self.device)), s)
     _lib.call('cg_gp_finalize', nets._p(norm), nets._p(st['gp'][slot:]),
               nets._p(st['coef_gp']), B, self.penalty, squared, s)
     if self.dis_optimizer.loss_scale is not None:
@@ -242,7 +243,8 @@ class WGAN_GP(GAN):
       _lib.call('cg_scale_rows', nets._p(plan.gin), nets._p(st['coef_gp']),
                 nets._p(st['dws'].act[0][2 * B:]), B, n, s)
     plan.jvp_forward()
-    net_d.params.grad.zero_()
+    if not nets.DETERMINISTIC:  # (the ordered reductions store every gradient)
+      net_d.params.grad.zero_()
     # bias gradients: real + fake segments only (the penalty has none)
     plan.weight_grads(bias_rows=2 * B)
 
@@ -284,7 +286,8 @@ class WGAN_GP(GAN):
     _lib.call('cg_neg_mean', nets._p(st['dws'].d_out), nets._p(st['gen_loss']),
               B, s)
     plan.backward_chain()
-    net_g.params.grad.zero_()
+    if not nets.DETERMINISTIC:
+      net_g.params.grad.zero_()
     st['gws'].backward(plan.gin)
 
   def _gen_metrics(self, real):
@@ -356,10 +359,10 @@ class WGAN_GP(GAN):
     def last_seg():
       metrics = self._gen_apply(real, lr(n), metrics=box.pop('metrics'))
       o = st['out']
-      o[0:1].copy_(st['gen_loss'])
-      o[1:2].copy_(st['loss'][:n, 0].mean(0, keepdim=True))
-      o[2:3].copy_(st['gp'][:n].mean(0, keepdim=True))
-      o[3:7].copy_(torch.stack([metrics[k] for k in _METRIC_KEYS]))
+      # (metrics are views of one 4-float buffer: GAN.metrics)
+      _lib.call('cg_step_outputs', nets._p(st['gen_loss']), nets._p(st['loss']),
+                nets._p(st['gp']), nets._p(metrics[_METRIC_KEYS[0]]), n,
+                nets._p(o), nets._stream())
       out['value'] = o
 
     segs = []

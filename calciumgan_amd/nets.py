@@ -97,6 +97,31 @@ class FlatParams(object):
       v.copy_(torch.from_numpy(w))
 
 
+# Ordered reductions (default).  Every sum that used to meet through f32 atomics
+# -- the penalty norm, conv / LayerNorm / Dense bias and scale gradients, the
+# critic head's weight gradient, the signal metrics -- goes through per-block
+# partial rows and a finishing launch that adds them in a fixed order and STORES
+# the result: a process replays itself bit for bit (with CALCIUMGAN_AUTOTUNE=0 or
+# a loaded tile table also across processes), and no gradient buffer needs
+# zeroing.  CALCIUMGAN_DETERMINISTIC=0: the atomics (+= onto zeroed buffers).
+DETERMINISTIC = __import__('os').environ.get('CALCIUMGAN_DETERMINISTIC',
+                                              '1') != '0'
+_REDUCE_WS = {}
+
+
+def reduce_ws(device):
+  """The shared workspace of the ordered reductions (cg_reduce_ws_elems floats,
+  one per device and precision: launches are stream-ordered), or None."""
+  if not DETERMINISTIC:
+    return None
+  key = (str(device), _lib.active())
+  ws = _REDUCE_WS.get(key)
+  if ws is None:
+    n = _lib.load().cg_reduce_ws_elems()
+    ws = _REDUCE_WS[key] = torch.empty(n, dtype=torch.float32, device=device)
+  return ws
+
+
 # CALCIUMGAN_NARROW_LAST=0: padded channel chunks are walked in full
 _NARROW_LAST = __import__('os').environ.get('CALCIUMGAN_NARROW_LAST', '1') != '0'
 
@@ -269,6 +294,13 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
     d.ln_eps = LN_EPS
     d.tile = 6  # CG_TILE_128x128_M32
   _autotune_tile(d)
+  if rowsumsq is not None and DETERMINISTIC and x.is_cuda:
+    # ordered penalty norm: one slot per workgroup of the chosen tile
+    need = _lib.load().cg_rowsumsq_ws_elems(ctypes.byref(d))
+    if need > 0:
+      wsq = torch.empty(need, dtype=torch.float32, device=x.device)
+      d._keep = d._keep + (wsq,)
+      d.rowsumsq_ws, d.rowsumsq_ws_elems = wsq.data_ptr(), need
   return d
 
 
@@ -538,6 +570,12 @@ def _wgrad_desc(x, g, dw, nB, Lx, Cx, Lu, Cg, taps, stride, off, Cx_real,
         _PARTIALS_POOL[(slot, need)] = buf
       d._keep = d._keep + (buf,)
       d.partials, d.partials_elems = buf.data_ptr(), need
+      d.store = 1 if DETERMINISTIC else 0
+    elif need == 0 and DETERMINISTIC:
+      # one K' split (or the taps == 1 form, pinned to one): every dw element
+      # has a single owner, stored directly
+      d.nsplit = 1
+      d.store = 1
   return d
 
 
@@ -853,8 +891,8 @@ class _DisPlan(object):
                   _p(ws.delta[i]), _p(self.shifts[i - 1]), self.nB, lay.lout,
                   lay.coutp, self.seg_size, net.alpha, st)
     if self.input_grad is not None:
-      if self.sumsq is not None:
-        self.sumsq.zero_()
+      if self.sumsq is not None and not self.input_grad.rowsumsq_ws:
+        self.sumsq.zero_()  # (the atomics form adds into it)
       _run_conv(self.input_grad, st)
 
   def jvp_forward(self):
@@ -875,7 +913,7 @@ class _DisPlan(object):
     _lib.call('cg_dense1_wgrad', _p(ws.act[-1]), _p(self.coef),
               _p(self.bias_coef), _p(net.params.grad_views[-2]),
               _p(net.params.grad_views[-1]), self.nB, last.lout, last.cout,
-              last.coutp, self.seg_size, st)
+              last.coutp, self.seg_size, _p(reduce_ws(net.device)), st)
 
 
 # ===========================================================================
@@ -1047,9 +1085,12 @@ class _GenWorkspace(object):
         self.dz, net.w_out_t.buf, self.dh[-1], B, net.L, net.Cp, 1, 1, 0, net.L,
         net.C, net.L, net.Cp, net.w_out_t.CK)
     # (partial tiles of the output Dense's weight gradient: cg_dense_wgrad)
+    # (always for the ordered form; else only when dW has at most four 128 x 128
+    # tiles, where a thousand workgroups' atomics on the same addresses serialise)
     need = _lib.load().cg_dense_wgrad_ws_elems(B * net.L, net.C, net.C)
+    few_tiles = ((net.C + 127) // 128)**2 <= 4
     self.out_wgrad_ws = (torch.empty(need, dtype=torch.float32, device=dev)
-                         if need > 0 else None)
+                         if need > 0 and (DETERMINISTIC or few_tiles) else None)
     self.b_dgrad, self.b_wgrad = [], []
     for i, (lay, ic) in enumerate(zip(net.layers, net.idx_conv)):
       op = net.w_dgrad[i]
@@ -1063,7 +1104,7 @@ class _GenWorkspace(object):
                       lay.lin, lay.cinp, k, 2, -net.pl, lay.cout, lay.cin,
                       slot=i))
     self.b_in_wgrad = _wgrad_desc(self.z, self.dy[0], G[0], B, 1, nd, 1,
-                                  w0 * nd, 1, 1, 0, nd, w0 * nd)
+                                  w0 * nd, 1, 1, 0, nd, w0 * nd, slot='in')
 
   def forward(self, z_f32, keep=True):
     """z (B, nd) f32 device -> self.fake (B, L, Cf) f32 (first C channels).
@@ -1112,8 +1153,9 @@ class _GenWorkspace(object):
     _lib.call('cg_dense_wgrad', _p(self.h[-1]), _p(self.dz), _p(G[net.idx_out]),
               rows, net.Cp, net.Cp, net.C, net.C, _p(self.out_wgrad_ws),
               0 if self.out_wgrad_ws is None else self.out_wgrad_ws.numel(), st)
+    rws = _p(reduce_ws(net.device))
     _lib.call('cg_colsum', _p(self.dz), _p(G[net.idx_out + 1]), rows, net.C,
-              net.Cp, st)
+              net.Cp, rws, st)
     if net.streaming_out_dgrad:
       _lib.call('cg_dense_rows_act', _p(self.dz), _p(net.w_out_t.buf),
                 _p(self.dh[-1]), rows, net.Cp, net.C, net.Cp, st)
@@ -1127,18 +1169,19 @@ class _GenWorkspace(object):
                   _p(self.ypre[i + 1]), _p(self.mean[i + 1]),
                   _p(self.rstd[i + 1]), _p(V[ic + 2]), _p(self.dy[i + 1]),
                   _p(G[ic + 2]), _p(G[ic + 3]), _p(G[ic + 1]), n, lay.cout,
-                  lay.coutp, net.alpha, st)
+                  lay.coutp, net.alpha, rws, st)
       else:
         _lib.call('cg_lrelu_bwd', _p(self.dh[i + 1]), _p(self.h[i + 1]),
                   _p(self.dy[i + 1]), n * lay.coutp, net.alpha, st)
         _lib.call('cg_colsum', _p(self.dy[i + 1]), _p(G[ic + 1]), n, lay.cout,
-                  lay.coutp, st)
+                  lay.coutp, rws, st)
       _run_conv(self.b_dgrad[i], st)
     nflat = net.w0 * net.nd
     _lib.call('cg_lrelu_bwd', _p(self.dh[0]), _p(self.h[0]), _p(self.dy[0]),
               self.B * nflat, net.alpha, st)
     _run_wgrad(self.b_in_wgrad, st)
-    _lib.call('cg_colsum', _p(self.dy[0]), _p(G[1]), self.B, nflat, nflat, st)
+    _lib.call('cg_colsum', _p(self.dy[0]), _p(G[1]), self.B, nflat, nflat, rws,
+              st)
     # the conv-transpose weight gradients read h[i] / dy[i+1], which the chain
     # above only produced: all of them together, at the end
     _run_wgrads(self.b_wgrad, st)

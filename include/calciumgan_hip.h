@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 15
+#define CG_ABI_VERSION 16
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -183,9 +183,19 @@ typedef struct cg_conv_desc {
    * it is gone (wgan_gp.py, _critic_compute).  Software-pipelined tiles only,
    * no split-K, not with the fused LayerNorm; null: off. */
   const float* row_scale;
+  /* Ordered penalty norm: with a workspace of >= cg_rowsumsq_ws_elems(d) floats
+   * every workgroup STORES its share of a sample's sum of squares in its own
+   * slot and a finishing launch adds a sample's slots in slot order and stores
+   * rowsumsq[b] -- the same bits every run, no zeroed buffer -- instead of one
+   * f32 atomic per workgroup into rowsumsq[b].  NULL: atomics (+=). */
+  float* rowsumsq_ws;
+  long long rowsumsq_ws_elems;
 } cg_conv_desc;
 
 int cg_swconv(const cg_conv_desc* d, void* stream);
+/* floats of cg_conv_desc.rowsumsq_ws for this descriptor's tile (0: no rowsumsq;
+ * < 0: invalid descriptor) */
+long long cg_rowsumsq_ws_elems(const cg_conv_desc* d);
 /* Validate a descriptor exactly as cg_swconv would (geometry, tile, LDS budget,
  * epilogue / split-K constraints) without launching anything: 0 or CG_EINVAL.
  * The host uses it before adopting a tile choice from a saved table. */
@@ -209,14 +219,16 @@ int cg_dense_rows(const void* x, const void* w, const float* bias, float* y,
  * 512}, N <= Cy, Cy % 8 == 0; columns [N, Cy) are written as zeros. */
 int cg_dense_rows_act(const void* x, const void* w, void* y, long long rows,
                       int Cx, int N, int Cy, void* stream);
-/* Weight gradient of that Dense: dW[cx][cg] += sum_r x[r][cx] * g[r][cg], dW f32
- * [Cx_real][Cg_real] row-major (the Keras kernel layout; the caller zeroes it),
- * x [rows][Cx], g [rows][Cg] bf16 / fp16, pitches multiples of 8.  Streaming
- * form: 128 x 128 tiles of dW x row ranges, K'-major operands through LDS
- * transpose reads.  The row ranges' partial tiles meet through f32 atomics, or
- * -- with a workspace of cg_dense_wgrad_ws_elems(...) floats (> 0 when dW has
- * at most four tiles, where a thousand workgroups' atomics on the same
- * addresses would serialise) -- through plain stores and a reducing launch. */
+/* Weight gradient of that Dense, dW f32 [Cx_real][Cg_real] row-major (the Keras
+ * kernel layout), x [rows][Cx], g [rows][Cg] bf16 / fp16, pitches multiples of
+ * 8.  Streaming form: 128 x 128 tiles of dW x row ranges, K'-major operands
+ * through LDS transpose reads.  ws == NULL: the row ranges' partial tiles meet
+ * through f32 atomics, dW[cx][cg] += sum_r x[r][cx] * g[r][cg] (the caller
+ * zeroes dW).  With a workspace of cg_dense_wgrad_ws_elems(...) floats: plain
+ * stores and a reducing launch that adds the ranges in a fixed order and STORES
+ * dW -- the only sensible form when dW has at most four tiles (a thousand
+ * workgroups' atomics on the same addresses serialise), and the deterministic
+ * one for any size. */
 long long cg_dense_wgrad_ws_elems(long long rows, int Cx_real, int Cg_real);
 int cg_dense_wgrad(const void* x, const void* g, float* dw, long long rows,
                    int Cx, int Cg, int Cx_real, int Cg_real, float* ws,
@@ -289,15 +301,20 @@ typedef struct cg_wgrad_desc {
                         from the g tiles already staged in LDS */
   long long bias_rows;
   float* partials;   /* optional workspace of >= cg_wgrad_partials_elems(d) f32:
-                        the K' splits then leave their partial sums with plain
-                        stores and a second kernel adds them into dw (one owner
-                        per element: deterministic), instead of every split
-                        adding into dw with f32 atomics.  NULL: atomics. */
+                        the K' splits then leave their partial sums (dw tiles
+                        and, with dbias, their bias column sums) with plain
+                        stores and a second kernel adds them in split order (one
+                        owner per element: deterministic), instead of every
+                        split adding into dw / dbias with f32 atomics.  NULL:
+                        atomics. */
   long long partials_elems;
+  int store;         /* with `partials`: dw (and dbias) are STORED, not added to
+                        (no zeroed buffer needed).  0: += as before. */
 } cg_wgrad_desc;
 int cg_wgrad(const cg_wgrad_desc* d, void* stream);
-/* f32 elements of `partials` this descriptor needs (0: the launch has a single
- * K' split or is the taps == 1 form, which always uses atomics); < 0: error */
+/* f32 elements of `partials` this descriptor needs (0: the taps == 1 form, which
+ * adds each dw element once per K' split with atomics -- one split, nsplit = 1,
+ * is deterministic); < 0: error */
 long long cg_wgrad_partials_elems(const cg_wgrad_desc* d);
 /* n weight gradients (independent layers of one backward pass) as ONE launch
  * when they are all the pipelined stride-2 form with the same tap count (the
@@ -325,14 +342,22 @@ int cg_ln_lrelu_fwd(const void* y_pre /*bf16 [rows][Cp]*/, const float* gamma,
                     float* mean /*[rows] or NULL*/, float* rstd /*[rows] or NULL*/,
                     long long rows, int C, int Cp, float eps, float alpha,
                     void* stream);
+/* Ordered reductions.  The functions below that reduce over rows take a
+ * workspace `ws` of cg_reduce_ws_elems() floats (one size for every function and
+ * shape; launches are stream-ordered, so one buffer serves them all).  With it,
+ * every block STORES a partial row and a finishing launch adds the rows in a
+ * fixed order and STORES the result: the same bits every run and no zeroed
+ * output.  ws == NULL: blocks meet through f32 atomics (+= into outputs the
+ * caller zeroed; the order, and so the last bits, vary from run to run). */
+long long cg_reduce_ws_elems(void);
 /* dy = d(loss)/d(y_pre); dgamma/dbeta (and, when dbias != NULL, the bias
- * gradient of the producing conv = column sums of dy) accumulated with f32
- * atomics. */
+ * gradient of the producing conv = column sums of dy): stored (ws) or
+ * accumulated with f32 atomics (ws == NULL). */
 int cg_ln_lrelu_bwd(const void* dh /*bf16*/, const void* h /*bf16*/,
                     const void* y_pre /*bf16*/, const float* mean,
                     const float* rstd, const float* gamma, void* dy /*bf16*/,
                     float* dgamma, float* dbeta, float* dbias, long long rows,
-                    int C, int Cp, float alpha, void* stream);
+                    int C, int Cp, float alpha, float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Discriminator head: Flatten + Dense(1) (calciumgan.py:188-190).
@@ -348,11 +373,12 @@ int cg_dense1_bwd(const float* w, const float* coef /*device [nseg]*/,
                   const void* h, void* delta /*bf16*/, int nB, int Lt, int C,
                   int Cp, int seg_size, float alpha, void* stream);
 /* dw[t*C+c] += sum_b coef[b / seg_size] * x[b][t][c];
- * db[0] += sum_b bias_coef[b / seg_size]  (bias_coef may be NULL) */
+ * db[0] += sum_b bias_coef[b / seg_size]  (bias_coef may be NULL);
+ * with ws: = instead of += (ordered reduction, see cg_reduce_ws_elems) */
 int cg_dense1_wgrad(const void* x /*bf16 [nB][Lt][Cp]*/, const float* coef,
                     const float* bias_coef /*device [nseg]*/, float* dw,
                     float* db, int nB, int Lt, int C, int Cp, int seg_size,
-                    void* stream);
+                    float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Backward of LeakyReLU + PhaseShuffle between discriminator layers:
@@ -378,7 +404,8 @@ int cg_cast_pad(const float* src, void* dst, long long rows, int C, int Cs,
                 int Cp, void* stream);
 /* norm[b] = ||g[b]||_2 over n elements (wgan_gp.py:49), g bf16 [B][n] (the
  * layer-1 input gradient, stored like every other activation gradient) */
-int cg_rownorm(const void* g, float* norm, int B, long long n, void* stream);
+int cg_rownorm(const void* g, float* norm, int B, long long n,
+               float* ws /* ordered reduction, or NULL */, void* stream);
 /* gp = mean((norm-1)^2) (wgan_gp.py:50); coef[b] = scale*2*(norm-1)/(B*norm).
  * squared != 0: `norm` holds sums of squares on entry and is replaced by their
  * square roots. */
@@ -394,9 +421,10 @@ int cg_critic_loss(const float* d_out, const float* gp, float penalty,
 /* out[0] = -mean(d_out[0:B])  (wgan_gp.py:19-20) */
 int cg_neg_mean(const float* d_out, float* out, int B, void* stream);
 
-/* out f32[C] += column sums of x bf16 [rows][Cp] (bias gradients) */
+/* out f32[C] += column sums of x bf16 [rows][Cp] (bias gradients); with ws:
+ * = instead of += (ordered reduction) */
 int cg_colsum(const void* x, float* out, long long rows, int C, int Cp,
-              void* stream);
+              float* ws, void* stream);
 /* dz = dfake * s * (1 - s)  (sigmoid backward; calciumgan.py:98-99) */
 int cg_sigmoid_bwd(const void* dfake /*bf16 [rows][Cp]*/,
                    const float* fake /*f32 [rows][Cf]*/,
@@ -442,12 +470,21 @@ int cg_loss_scale_update(float* ls, int growth_interval, void* stream);
  * GAN.metrics (gan/algorithms/gan.py:32-41, gan/utils/signals_metrics.py:9-28):
  * out[0..3] += sum over rows of squared differences of per-row (min, max,
  * mean, population-std) over channels of denormalised real vs fake; caller
- * zeroes out and divides by rows.
+ * zeroes out and divides by rows (ws == NULL); with ws the MEANS over rows are
+ * stored (ordered reduction, see cg_reduce_ws_elems).
  * ------------------------------------------------------------------------- */
 int cg_signal_metrics(const float* real /*[rows][Cr]*/,
                       const float* fake /*[rows][Cf]*/, float* out,
                       long long rows, int C, int Cr, int Cf, float smin,
-                      float smax, void* stream);
+                      float smax, float* ws, void* stream);
+
+/* The scalars WGAN_GP.train returns (gan/algorithms/wgan_gp.py:82-95), gathered
+ * by one launch: out[0] = gen_loss[0], out[1] = mean_k loss[2 k] (the critic loss
+ * of update k; loss is f32 [n][2] as cg_critic_loss writes it), out[2] = mean_k
+ * gp[k], out[3..6] = metrics[0..3]. */
+int cg_step_outputs(const float* gen_loss, const float* loss, const float* gp,
+                    const float* metrics, int n, float* out /*[7]*/,
+                    void* stream);
 
 #ifdef __cplusplus
 }

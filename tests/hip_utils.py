@@ -82,3 +82,24 @@ def run_wgrad(d):
 
 def sync():
   torch.cuda.synchronize()
+
+
+_WS = {}
+
+
+def reduce_ws():
+  """Workspace of the ordered reductions (cg_reduce_ws_elems floats), filled
+  with NaN: a kernel that read a slot nobody wrote would show it."""
+  if 'ws' not in _WS:
+    _WS['ws'] = torch.empty(_lib.load().cg_reduce_ws_elems(), dtype=torch.float32,
+                            device=DEV)
+  _WS['ws'].fill_(float('nan'))
+  return _WS['ws']
+
+
+def out_buffers(ws, *shapes):
+  """Output tensors of a reducing kernel: zeros for the atomics form (it adds),
+  a poison value for the ordered form (it must store)."""
+  fill = 0.0 if ws is None else 12345.0
+  return [torch.full(s if isinstance(s, tuple) else (s,), fill, device=DEV)
+          for s in shapes]

@@ -172,16 +172,17 @@ def test_signal_metrics_and_layernorm_at_full_size():
   cp = geo.pitch(C)
   fake = torch.zeros(B, L, cp)
   fake[:, :, :C] = torch.rand(B, L, C, generator=gen)
-  buf = torch.zeros(4, device=H.DEV)
   real_d, fake_d = real.to(H.DEV), fake.to(H.DEV)
-  _lib.call('cg_signal_metrics', H.p(real_d), H.p(fake_d), H.p(buf), B * L, C,
-            C, cp, -0.5, 2.5, H.stream())
-  H.sync()
   ref = O.signal_metrics(real, fake[:, :, :C], -0.5, 2.5, True)
-  got = buf.cpu().numpy() / (B * L)
   exp = [ref['signals_metrics/' + k].item() for k in ('min', 'max', 'mean',
                                                       'std')]
-  np.testing.assert_allclose(got, exp, rtol=2e-4)
+  for ws in (None, H.reduce_ws()):
+    (buf,) = H.out_buffers(ws, 4)
+    _lib.call('cg_signal_metrics', H.p(real_d), H.p(fake_d), H.p(buf), B * L, C,
+              C, cp, -0.5, 2.5, H.p(ws), H.stream())
+    H.sync()
+    got = buf.cpu().numpy() / (B * L if ws is None else 1)
+    np.testing.assert_allclose(got, exp, rtol=2e-4)
   # LayerNorm + LeakyReLU over all 262 144 rows: rows of the normalised
   # pre-activation have mean beta-weighted 0 / variance 1 (gamma = 1, beta = 0)
   rows = B * L
@@ -206,3 +207,94 @@ def test_signal_metrics_and_layernorm_at_full_size():
   assert float(xh.mean(1).abs().max()) < 2e-2      # bf16 output rounding
   assert abs(float(xh.var(1, unbiased=False).mean()) - 1.0) < 1e-2
   assert float(h[:, C:].float().abs().max()) == 0.0
+
+
+# -- the specialised epilogues of the 32-row wave tiles at the benchmark's sizes --
+# (nB, L, Ci, Co): the critic's five layers over its 3 x 128 batch
+_CRITIC = [(384, 2048, 102, 64), (384, 1024, 64, 128), (384, 512, 128, 192),
+           (384, 256, 192, 256), (384, 128, 256, 320)]
+
+
+def _swp_vs_classic(make_desc, outputs, tile):
+  """The same descriptor on the classic 256 x 64 tile kernel (run-time epilogue)
+  and on software-pipelined tile `tile` (specialised epilogue), twice: every
+  output tensor equal bit for bit."""
+  import ctypes
+  got = []
+  for t in (0, tile, tile):
+    for o in outputs:
+      o.fill_(7.0)
+    d = make_desc()
+    d.tile, d.stage_ksteps, d.split_parity, d.ksplit = t, 2, 0, 0
+    rc = _lib.load().cg_swconv(ctypes.byref(d), H.stream())
+    if rc == _lib.CG_EINVAL:
+      pytest.skip('tile not admissible for this shape')
+    assert rc == 0
+    H.sync()
+    got.append([o.clone() for o in outputs])
+  for ref, a, b in zip(*got):
+    bad = int((ref.float() != a.float()).sum()) + int((ref.float() != b.float()).sum())
+    assert bad == 0, '%d elements differ from the classic tile' % bad
+
+
+@pytest.mark.parametrize('tile', [13, 14, 15])
+@pytest.mark.parametrize('nB,L,Ci,Co', _CRITIC)
+def test_lean_epilogues_equal_the_classic_tiles_at_full_size(tile, nB, L, Ci, Co):
+  """Round 4's specialised epilogues (bias + LeakyReLU, LeakyReLU' mask in
+  place, mask + PhaseShuffle adjoint) against the classic tile kernel on
+  small-integer data at the critic's full layer sizes.  The small kernel tests
+  cannot see what this one is for: a 16-byte buffer store whose data registers
+  the compiler let the next instructions overwrite (scalar offset in the
+  store: swconv_swp.hip, store_rows) lost about one element in 10^4, only under
+  the memory back-pressure of a full-size launch."""
+  nets_autotune = nets._AUTOTUNE
+  nets._AUTOTUNE = False
+  try:
+    gen = torch.Generator(device=H.DEV)
+    gen.manual_seed(99)
+    k = 24
+    cip, cop = geo.pitch(Ci), geo.pitch(Co)
+    pl = geo.same_padding_left(k, 2)
+    x = _pitched(_rand_int(gen, (nB, L, Ci), -2, 2), cip)
+    W = _rand_int(gen, (k, Ci, Co), -1, 1, 0.5)
+    bias = _rand_int(gen, (Co,), -2, 2)
+    ck = nets._ck_for(cip, 2, k, L // 2)
+    op = H.pack(W, [(0, 1, Ci * Co, Co, 1)], Ci, Co, cip, ck, k, parity_major=True)
+    shifts = torch.tensor([3, -7, 10], dtype=torch.int32, device=H.DEV)
+    # forward: bias + LeakyReLU (kEpiLrelu), fused input-side PhaseShuffle
+    y = torch.empty(nB, L // 2, cop, dtype=BF16, device=H.DEV)
+    _swp_vs_classic(
+        lambda: H.conv_desc(x, op.buf, y, nB, L, cip, k, 2, -pl, L // 2, Co,
+                            L // 2, cop, ck, bias=bias, shifts=shifts,
+                            seg_size=128, epilogue=_lib.EPI_LRELU,
+                            w_parity_major=True, w_narrow_last=op.narrow_last),
+        [y], tile)
+    # tangent form: LeakyReLU' mask read from another tensor (kEpiMask)
+    h = _pitched(_rand_int(gen, (nB, L // 2, Co), -2, 2), cop)
+    _swp_vs_classic(
+        lambda: H.conv_desc(x, op.buf, y, nB, L, cip, k, 2, -pl, L // 2, Co,
+                            L // 2, cop, ck, mask_src=h, shifts=shifts,
+                            seg_size=128, epilogue=_lib.EPI_MASK,
+                            w_parity_major=True, w_narrow_last=op.narrow_last),
+        [y], tile)
+    # input gradient: two phases, mask + output-side PhaseShuffle adjoint
+    # (kEpiMaskShift), reflected rows through the side buffer
+    phases = nets._transpose_phases(k, pl)
+    ckd = nets._ck_for(cop, 1, k // 2, L // 2)
+    opd = H.pack(W, [(t0, -2, Ci * Co, 1, Co) for t0, _ in phases], Co, Ci, cop,
+                 ckd, k // 2)
+    g = _pitched(_rand_int(gen, (nB, L // 2, Co), -2, 2), cop)
+    hx = _pitched(_rand_int(gen, (nB, L, Ci), -2, 2), cip)
+    e = torch.empty(nB, L, cip, dtype=BF16, device=H.DEV)
+    side = torch.empty(nB, 10, cip, dtype=BF16, device=H.DEV)
+    offs = [o for _, o in phases]
+    _swp_vs_classic(
+        lambda: H.conv_desc(g, opd.buf, e, nB, L // 2, cop, k // 2, 1, offs[0],
+                            L // 2, Ci, L, cip, ckd, y_stride=2, y_off=0, nphase=2,
+                            w_phase_stride=opd.elems,
+                            off_phase_step=offs[1] - offs[0], yoff_phase_step=1,
+                            mask_src=hx, epilogue=_lib.EPI_MASK,
+                            out_shifts=(shifts, 128, side, 10)),
+        [e, side], tile)
+  finally:
+    nets._AUTOTUNE = nets_autotune

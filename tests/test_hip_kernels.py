@@ -291,8 +291,23 @@ def test_conv_dgrad_every_tile(tile, ks, nB, L, Ci, Co, k):
   if cip > Ci:
     assert float(got[:, :, Ci:].abs().max()) == 0.0
   if ssq is not None:
-    np.testing.assert_allclose(ssq.cpu().numpy(),
-                               (ref**2).sum(dim=(1, 2)).numpy(), rtol=1e-5)
+    want = (ref**2).sum(dim=(1, 2)).numpy()
+    np.testing.assert_allclose(ssq.cpu().numpy(), want, rtol=1e-5)
+    # the ordered form: one slot per workgroup, summed by a finishing launch and
+    # STORED (the output starts poisoned); twice the same bits
+    d.tile, d.stage_ksteps = tile, ks
+    need = _lib.load().cg_rowsumsq_ws_elems(ctypes.byref(d))
+    assert need > 0
+    wsq = torch.full((need,), float('nan'), device=H.DEV)
+    d.rowsumsq_ws, d.rowsumsq_ws_elems = wsq.data_ptr(), need
+    runs = []
+    for _ in range(2):
+      ssq.fill_(12345.0)
+      H.run_conv(d)
+      H.sync()
+      runs.append(ssq.clone())
+    np.testing.assert_allclose(runs[0].cpu().numpy(), want, rtol=1e-5)
+    assert torch.equal(runs[0], runs[1])
 
 
 DGRAD_CASES = [
@@ -569,25 +584,27 @@ def test_dense_rows_wide(rows, Ci, Co, epi):
 @pytest.mark.parametrize('rows,Ci,Co', [(4096, 102, 102), (70, 32, 256),
                                         (33000, 512, 512), (1000, 130, 40)])
 def test_dense_wgrad_streaming(rows, Ci, Co):
-  """cg_dense_wgrad: dW += x^T g for the per-timestep Dense, exact on integer
-  data whatever the number of 128 x 128 tiles and row ranges (partial tiles
-  meet through f32 atomics: integer sums are order-independent); ragged row
-  count; accumulates into dW."""
+  """cg_dense_wgrad: dW (+)= x^T g for the per-timestep Dense, exact on integer
+  data whatever the number of 128 x 128 tiles and row ranges; ragged row count.
+  Without a workspace the partial tiles meet through f32 atomics and accumulate
+  into dW; with one they are added in a fixed order and dW is stored."""
   rng = np.random.RandomState(23)
   cip, cop = geo.pitch(Ci), geo.pitch(Co)
   x = H.int_tensor(rng, (1, rows, Ci), -2, 2)
   g = H.int_tensor(rng, (1, rows, Co), -2, 2)
   xd, gd = H.to_pitch(x, cip), H.to_pitch(g, cop)
-  ref = x[0].double().t() @ g[0].double() + 3.0
+  ref = x[0].double().t() @ g[0].double()
   need = _lib.load().cg_dense_wgrad_ws_elems(rows, Ci, Co)
-  assert (need > 0) == (((Ci + 127) // 128) * ((Co + 127) // 128) <= 4)
-  ws = torch.full((max(need, 1),), float('nan'), device=H.DEV)
-  for use_ws in ([False, True] if need > 0 else [False]):
+  assert need > 0
+  ws = torch.full((need,), float('nan'), device=H.DEV)
+  for use_ws in (False, True):
     dw = torch.full((Ci, Co), 3.0, dtype=torch.float32, device=H.DEV)
     _lib.call('cg_dense_wgrad', H.p(xd), H.p(gd), H.p(dw), rows, cip, cop, Ci,
               Co, H.p(ws) if use_ws else None, need if use_ws else 0, H.stream())
     H.sync()
-    np.testing.assert_array_equal(dw.cpu().double().numpy(), ref.numpy())
+    # (+= onto the 3.0 without a workspace, = with one)
+    np.testing.assert_array_equal(dw.cpu().double().numpy(),
+                                  ref.numpy() + (0.0 if use_ws else 3.0))
 
 
 WGRAD_CASES = [
@@ -708,25 +725,34 @@ def test_layernorm_lrelu_fwd_bwd(rows, C):
   hq = h.float().cpu()[:, :, :C]
   mask = torch.where(hq > 0, 1.0, ALPHA)
   (O.layer_norm(yq, g_, b_) * (dhq * mask)).sum().backward()
-  dy = torch.zeros(1, rows, cp, dtype=BF16, device=H.DEV)
-  dg = torch.zeros(C, device=H.DEV)
-  db = torch.zeros(C, device=H.DEV)
-  dbias = torch.zeros(C, device=H.DEV)
-  _lib.call('cg_ln_lrelu_bwd', H.p(dhd), H.p(h), H.p(yd), H.p(mean), H.p(rstd),
-            H.p(gd), H.p(dy), H.p(dg), H.p(db), H.p(dbias), rows, C, cp, ALPHA,
-            H.stream())
-  H.sync()
-  np.testing.assert_allclose(
-      dy.float().cpu()[0, :, :C].numpy(), yq.grad[0].numpy(), rtol=2e-2,
-      atol=2e-2)
-  np.testing.assert_allclose(dg.cpu().numpy(), g_.grad.numpy(), rtol=1e-3,
-                             atol=1e-3)
-  np.testing.assert_allclose(db.cpu().numpy(), b_.grad.numpy(), rtol=1e-3,
-                             atol=1e-3)
-  # fused bias gradient of the producing conv = column sums of the stored dy
-  np.testing.assert_allclose(dbias.cpu().numpy(),
-                             dy.float().cpu()[0, :, :C].sum(0).numpy(),
-                             rtol=1e-4, atol=1e-4)
+  # ws None: f32 atomics into zeroed outputs; else the ordered reduction, which
+  # stores (outputs start poisoned) and repeats bit for bit
+  for ws in (None, H.reduce_ws()):
+    dy = torch.zeros(1, rows, cp, dtype=BF16, device=H.DEV)
+    dg, db, dbias = H.out_buffers(ws, C, C, C)
+    _lib.call('cg_ln_lrelu_bwd', H.p(dhd), H.p(h), H.p(yd), H.p(mean),
+              H.p(rstd), H.p(gd), H.p(dy), H.p(dg), H.p(db), H.p(dbias), rows, C,
+              cp, ALPHA, H.p(ws), H.stream())
+    H.sync()
+    np.testing.assert_allclose(
+        dy.float().cpu()[0, :, :C].numpy(), yq.grad[0].numpy(), rtol=2e-2,
+        atol=2e-2)
+    np.testing.assert_allclose(dg.cpu().numpy(), g_.grad.numpy(), rtol=1e-3,
+                               atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), b_.grad.numpy(), rtol=1e-3,
+                               atol=1e-3)
+    # fused bias gradient of the producing conv = column sums of the stored dy
+    np.testing.assert_allclose(dbias.cpu().numpy(),
+                               dy.float().cpu()[0, :, :C].sum(0).numpy(),
+                               rtol=1e-4, atol=1e-4)
+    if ws is not None:
+      first = [t.clone() for t in (dg, db, dbias)]
+      _lib.call('cg_ln_lrelu_bwd', H.p(dhd), H.p(h), H.p(yd), H.p(mean),
+                H.p(rstd), H.p(gd), H.p(dy), H.p(dg), H.p(db), H.p(dbias), rows,
+                C, cp, ALPHA, H.p(ws), H.stream())
+      H.sync()
+      for a, b in zip(first, (dg, db, dbias)):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize('nB,L,Ci,Co,k,seg,m', [(6, 128, 102, 64, 24, 2, 10),
@@ -843,16 +869,16 @@ def test_discriminator_head_kernels():
   refd = cb * wq.reshape(1, Lt, C) * torch.where(h > 0, 1.0, ALPHA)
   np.testing.assert_array_equal(
       delta.float().cpu()[:, :, :C].numpy(), refd.to(BF16).float().numpy())
-  dw = torch.zeros(Lt * C, device=H.DEV)
-  db = torch.zeros(1, device=H.DEV)
   bc = torch.tensor([-0.5, 0.5, 0.0]).to(H.DEV)
-  _lib.call('cg_dense1_wgrad', H.p(hd), H.p(cd), H.p(bc), H.p(dw), H.p(db), nB,
-            Lt, C, cp, seg, H.stream())
-  H.sync()
   refw = (cb * h).sum(0).reshape(-1)
-  np.testing.assert_allclose(dw.cpu().numpy(), refw.numpy(), rtol=1e-5,
-                             atol=1e-5)
-  np.testing.assert_allclose(db.cpu().numpy(), [0.0], atol=1e-6)
+  for ws in (None, H.reduce_ws()):
+    dw, db = H.out_buffers(ws, Lt * C, 1)
+    _lib.call('cg_dense1_wgrad', H.p(hd), H.p(cd), H.p(bc), H.p(dw), H.p(db), nB,
+              Lt, C, cp, seg, H.p(ws), H.stream())
+    H.sync()
+    np.testing.assert_allclose(dw.cpu().numpy(), refw.numpy(), rtol=1e-5,
+                               atol=1e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), [0.0], atol=1e-6)
 
 
 def test_wgan_gp_elementwise_kernels():
@@ -885,7 +911,12 @@ def test_wgan_gp_elementwise_kernels():
   norm = torch.zeros(B, device=H.DEV)
   gp = torch.zeros(1, device=H.DEV)
   coef = torch.zeros(B, device=H.DEV)
-  _lib.call('cg_rownorm', H.p(gd), H.p(norm), B, L * cp, H.stream())
+  (norm_o,) = H.out_buffers(True, B)
+  _lib.call('cg_rownorm', H.p(gd), H.p(norm_o), B, L * cp, H.p(H.reduce_ws()),
+            H.stream())
+  _lib.call('cg_rownorm', H.p(gd), H.p(norm), B, L * cp, None, H.stream())
+  H.sync()
+  np.testing.assert_allclose(norm_o.cpu().numpy(), norm.cpu().numpy(), rtol=1e-6)
   _lib.call('cg_gp_finalize', H.p(norm), H.p(gp), H.p(coef), B, 10.0, 0,
             H.stream())
   a0 = torch.zeros(B, L * cp, dtype=BF16, device=H.DEV)
@@ -936,20 +967,22 @@ def test_adam_colsum_sigmoid_lrelu_metrics():
   rows, C = 1000, 102
   cp = geo.pitch(C)
   x = H.int_tensor(rng, (1, rows, C), -3, 3)
-  out = torch.zeros(C, device=H.DEV)
   xd = H.to_pitch(x, cp)
-  _lib.call('cg_colsum', H.p(xd), H.p(out), rows, C, cp, H.stream())
-  H.sync()
-  np.testing.assert_array_equal(out.cpu().numpy(), x[0].sum(0).numpy())
+  for ws in (None, H.reduce_ws()):
+    (out,) = H.out_buffers(ws, C)
+    _lib.call('cg_colsum', H.p(xd), H.p(out), rows, C, cp, H.p(ws), H.stream())
+    H.sync()
+    np.testing.assert_array_equal(out.cpu().numpy(), x[0].sum(0).numpy())
   # rows wider than one 2048-channel slab (the generator's input Dense bias
   # gradient at sequence length 8192: 256 * 32 columns), and an odd tail slab
   for rows_w, cw in ((37, 8192), (300, 2080)):
     xw = H.int_tensor(rng, (1, rows_w, cw), -3, 3)
-    outw = torch.zeros(cw, device=H.DEV)
-    _lib.call('cg_colsum', H.p(H.to_pitch(xw, cw)), H.p(outw), rows_w, cw, cw,
-              H.stream())
-    H.sync()
-    np.testing.assert_array_equal(outw.cpu().numpy(), xw[0].sum(0).numpy())
+    for ws in (None, H.reduce_ws()):
+      (outw,) = H.out_buffers(ws, cw)
+      _lib.call('cg_colsum', H.p(H.to_pitch(xw, cw)), H.p(outw), rows_w, cw, cw,
+                H.p(ws), H.stream())
+      H.sync()
+      np.testing.assert_array_equal(outw.cpu().numpy(), xw[0].sum(0).numpy())
   # sigmoid bwd
   fake = torch.tensor(rng.rand(1, rows, C).astype(np.float32))
   dfake = torch.zeros(1, rows, cp)
@@ -967,16 +1000,18 @@ def test_adam_colsum_sigmoid_lrelu_metrics():
   # metrics
   real = torch.tensor(rng.rand(3, 50, C).astype(np.float32))
   fk = torch.tensor(rng.rand(3, 50, C).astype(np.float32))
-  buf = torch.zeros(4, device=H.DEV)
   real_d, fk_d = real.to(H.DEV), fk.to(H.DEV)
-  _lib.call('cg_signal_metrics', H.p(real_d), H.p(fk_d), H.p(buf), 150, C, C, C,
-            -1.0, 3.0, H.stream())
-  H.sync()
   refm = O.signal_metrics(real, fk, -1.0, 3.0, True)
-  got = buf.cpu().numpy() / 150
   exp = [refm['signals_metrics/' + k].item() for k in ('min', 'max', 'mean',
                                                         'std')]
-  np.testing.assert_allclose(got, exp, rtol=1e-4)
+  for ws in (None, H.reduce_ws()):
+    (buf,) = H.out_buffers(ws, 4)
+    _lib.call('cg_signal_metrics', H.p(real_d), H.p(fk_d), H.p(buf), 150, C, C,
+              C, -1.0, 3.0, H.p(ws), H.stream())
+    H.sync()
+    # (sums without a workspace; the ordered form stores the means)
+    got = buf.cpu().numpy() / (150 if ws is None else 1)
+    np.testing.assert_allclose(got, exp, rtol=1e-4)
 
 
 def test_wgrad_batched_equals_individual_launches():

@@ -31,6 +31,7 @@ def main():
   dev = 'cuda'
   st = nets._stream()
   B = 128
+  rws = torch.empty(_lib.load().cg_reduce_ws_elems(), device=dev)
   # generator LayerNorm layers: (rows, C, Cp)
   for L, C in ((128, 320), (256, 256), (512, 192), (1024, 128), (2048, 102)):
     rows, Cp = B * L, max(32, (C + 31) // 32 * 32)
@@ -50,12 +51,13 @@ def main():
     dg = torch.zeros(C, device=dev)
     db = torch.zeros(C, device=dev)
     dbias = torch.zeros(C, device=dev)
-    t = timeit(lambda: _lib.call('cg_ln_lrelu_bwd', P(dh), P(h), P(y), P(mean),
-                                 P(rstd), P(g), P(dy), P(dg), P(db), P(dbias),
-                                 rows, C, Cp, 0.3, st))
     nbytes = rows * Cp * 8 + rows * 8
-    print('ln_bwd rows %7d C %3d: %6.1f us  %.2f TB/s' % (rows, C, t * 1e6,
-                                                          nbytes / t / 1e12))
+    for label, ws in (('atomics', None), ('ordered', rws)):
+      t = timeit(lambda: _lib.call('cg_ln_lrelu_bwd', P(dh), P(h), P(y), P(mean),
+                                   P(rstd), P(g), P(dy), P(dg), P(db), P(dbias),
+                                   rows, C, Cp, 0.3, P(ws), st))
+      print('ln_bwd (%s) rows %7d C %3d: %6.1f us  %.2f TB/s' % (
+          label, rows, C, t * 1e6, nbytes / t / 1e12))
   # discriminator unshuffle + mask (3B batch)
   for w, C in ((1024, 64), (512, 128), (256, 192), (128, 256)):
     nB = 3 * B
@@ -73,15 +75,17 @@ def main():
   real = torch.rand(rows, C, device=dev)
   fake = torch.rand(rows, Cp, device=dev)
   out = torch.zeros(4, device=dev)
-  t = timeit(lambda: _lib.call('cg_signal_metrics', P(real), P(fake), P(out), rows,
-                               C, C, Cp, 0.0, 1.0, st))
-  print('signal_metrics rows %d: %6.1f us  %.2f TB/s' % (
-      rows, t * 1e6, rows * (C + Cp) * 4 / t / 1e12))
   dz = torch.randn(rows, Cp, device=dev).to(BF16)
   cs = torch.zeros(C, device=dev)
-  t = timeit(lambda: _lib.call('cg_colsum', P(dz), P(cs), rows, C, Cp, st))
-  print('colsum rows %d: %6.1f us  %.2f TB/s' % (rows, t * 1e6,
-                                                 rows * Cp * 2 / t / 1e12))
+  for label, ws in (('atomics', None), ('ordered', rws)):
+    t = timeit(lambda: _lib.call('cg_signal_metrics', P(real), P(fake), P(out),
+                                 rows, C, C, Cp, 0.0, 1.0, P(ws), st))
+    print('signal_metrics (%s) rows %d: %6.1f us  %.2f TB/s' % (
+        label, rows, t * 1e6, rows * (C + Cp) * 4 / t / 1e12))
+    t = timeit(lambda: _lib.call('cg_colsum', P(dz), P(cs), rows, C, Cp, P(ws),
+                                 st))
+    print('colsum (%s) rows %d: %6.1f us  %.2f TB/s' % (
+        label, rows, t * 1e6, rows * Cp * 2 / t / 1e12))
 
 
 if __name__ == '__main__':

@@ -98,7 +98,7 @@ if variant == 'memsetprobe':
       rc = hip.hipMemsetAsync(probe['buf'].data_ptr(), 0, 32, st_)
       assert rc == 0, rc
       orig_call('cg_colsum', nets._p(probe['ones']), nets._p(probe['buf']),
-                ROWS, 8, 8, st_)
+                ROWS, 8, 8, None, st_)
       probe['res'][probe['n'] % 5].copy_(probe['buf'])
       probe['n'] += 1
     return orig_call(name, *a)
