@@ -106,6 +106,7 @@ SIGNATURES = {
     'cg_act_dtype': [],
     'cg_struct_size': [c_i],
     'cg_tile_shape': [c_i, C.POINTER(c_i), C.POINTER(c_i)],
+    'cg_debug_lean_epilogue': [c_i],
     'cg_profile_enable': [c_i],
     'cg_profile_collect': [C.POINTER(c_f), C.POINTER(c_i), c_i],
     'cg_swconv': [C.POINTER(ConvDesc), c_vp],

@@ -120,7 +120,11 @@ __device__ __forceinline__ int sw64(int byte) {
 //                  or not), bf16 rows
 //   kEpiMaskShift  the same with the output-side PhaseShuffle adjoint
 //                  (cg_conv_desc.out_shifts): rows land at their source positions
-constexpr int kEpiGeneric = 0, kEpiLrelu = 1, kEpiMask = 2, kEpiMaskShift = 3;
+//   kEpiLreluSsq   kEpiLrelu + the penalty norm (cg_conv_desc.rowsumsq): the x^
+//                  input gradient's launch (its own form: the scalars it adds
+//                  cost the plain one registers inside the K loop)
+constexpr int kEpiGeneric = 0, kEpiLrelu = 1, kEpiMask = 2, kEpiMaskShift = 3,
+              kEpiLreluSsq = 4;
 
 // R: source stride.  WM x WN waves (4 or 8); wave tile (16 * MT) x 64.
 // LN: CG_EPI_LN_LRELU (LayerNorm + LeakyReLU in the epilogue; 128-column tiles).
@@ -1015,11 +1019,9 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
         for (int e = 0; e < 8; ++e)
           if (n + e >= a.N) v[e] = 0.f;
       }
-      if constexpr (EPI == kEpiLrelu) {
-        if (a.rowsumsq) {
+      if constexpr (EPI == kEpiLreluSsq) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
-        }
+        for (int e = 0; e < 8; ++e) ssq += v[e] * v[e];
       }
       return u32x4{pack2act(v[0], v[1]), pack2act(v[2], v[3]), pack2act(v[4], v[5]),
                    pack2act(v[6], v[7])};
@@ -1043,10 +1045,10 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
     // benchmark's shapes, none in the small kernel tests.  With soffset 0 the
     // compiler keeps its wait states; tests/test_hip_fullsize.py holds the case.)
     auto store_rows = [&](const u32x4 d, __amdgpu_buffer_rsrc_t r, int vofs, int mt) {
-      const int o = vofs == kOff ? kOff : vofs + mt * mt_step;
-      __builtin_amdgcn_raw_buffer_store_b128(d, r, o, 0, 0);
+      // (a switched-off lane stays past num_records: kOff + mt_step < 2^32)
+      __builtin_amdgcn_raw_buffer_store_b128(d, r, vofs + mt * mt_step, 0, 0);
     };
-    if constexpr (EPI == kEpiLrelu || EPI == kEpiMask) {
+    if constexpr (EPI == kEpiLrelu || EPI == kEpiLreluSsq || EPI == kEpiMask) {
       const long long base = (((long long)bw * a.Ly + t0) * a.Cy) * 2;
       const __amdgpu_buffer_rsrc_t ry = rsrc_at(a.y, base);
       const int voff = rM * a.y_stride * rowB + nl0 * 2;
@@ -1073,7 +1075,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
           pair8(mt, p, v);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += bv[p][e];
-          if constexpr (EPI == kEpiLrelu) {
+          if constexpr (EPI != kEpiMask) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], a.alpha * v[e]);
           } else {
@@ -1085,20 +1087,18 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
           }
           store_rows(finish8(v, nl0 + p * 32), ry, vo[p], mt);
         }
-      if constexpr (EPI == kEpiLrelu) {
-        if (a.rowsumsq) {
-          // the whole tile belongs to one sample (nseg == 1, checked on the
-          // host; every wave of the workgroup is here): the workgroup's own slot
-          // of the ordered sum, or one f32 atomic
-          ssq = wave_sum(ssq);
-          if (lane == 0) wsum[wave] = ssq;
-          __syncthreads();
-          if (tid == 0) {
-            float t = 0.f;
-            for (int w = 0; w < NW; ++w) t += wsum[w];
-            if (a.ssq_ws) a.ssq_ws[(long long)bw * a.ssq_P + to_sgpr(ess)] = t;
-            else atomicAdd(a.rowsumsq + bw, t);
-          }
+      if constexpr (EPI == kEpiLreluSsq) {
+        // the whole tile belongs to one sample (nseg == 1, checked on the host;
+        // every wave of the workgroup is here): the workgroup's own slot of the
+        // ordered sum, or one f32 atomic
+        ssq = wave_sum(ssq);
+        if (lane == 0) wsum[wave] = ssq;
+        __syncthreads();
+        if (tid == 0) {
+          float t = 0.f;
+          for (int w = 0; w < NW; ++w) t += wsum[w];
+          if (a.ssq_ws) a.ssq_ws[(long long)bw * a.ssq_P + to_sgpr(ess)] = t;
+          else atomicAdd(a.rowsumsq + bw, t);
         }
       }
     } else {
@@ -1361,12 +1361,22 @@ extern "C" int cg_debug_swp_trace(unsigned* dst, int n) {
 }
 #endif
 
-// CALCIUMGAN_SWP_GENERIC_EPI=1: every launch takes the run-time epilogue (A/B of
-// the lean forms inside one library; read once)
-static const bool g_swp_generic_epi = [] {
-  const char* e = getenv("CALCIUMGAN_SWP_GENERIC_EPI");
+// The specialised epilogues are OFF unless CALCIUMGAN_SWP_LEAN_EPI=1 (read once)
+// or cg_debug_lean_epilogue(1): measured on the cfg2 step they cut a wave's
+// boundary from ~8.5 k to ~2.6 k cycles per tile (profiles/r04_swp_wave_cycles.txt)
+// and the kernels take the SAME time to 1 % on every geometry, the step 2 % MORE
+// (profiles/r04_swp_lean_epilogue_ab.txt): the launches are not bound by what a
+// wave does at a tile boundary.  Kept for the record and for the tests that pin
+// the store hazard found on the way (store_rows).
+static bool g_swp_lean_epi = [] {
+  const char* e = getenv("CALCIUMGAN_SWP_LEAN_EPI");
   return e && e[0] == '1';
 }();
+extern "C" int cg_debug_lean_epilogue(int on) {
+  const int was = g_swp_lean_epi ? 1 : 0;
+  if (on >= 0) g_swp_lean_epi = on != 0;
+  return was;
+}
 
 int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
                       int ksplit, bool dry, hipStream_t stream) {
@@ -1428,10 +1438,11 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   // lean epilogue forms: the 32-row wave tiles (what the tuner picks for nearly
   // every cfg2 geometry), bf16 rows, no split-K / f32 output / penalty norm
   int epi = kEpiGeneric;
-  if (mt == 2 && !a.out_f32 && ksplit <= 1 && !g_swp_generic_epi) {
+  if (mt == 2 && !a.out_f32 && ksplit <= 1 && g_swp_lean_epi) {
     if ((a.epilogue == CG_EPI_NONE || a.epilogue == CG_EPI_LRELU) &&
         !a.out_shifts && !a.row_scale) {
-      epi = kEpiLrelu;  // (with or without the penalty norm)
+      epi = a.rowsumsq ? kEpiLreluSsq : kEpiLrelu;
+      if (epi == kEpiLreluSsq && stride != 1) epi = kEpiGeneric;
       if (a.epilogue == CG_EPI_NONE) pa.c.alpha = 1.f;  // max(v, v)
     } else if (a.rowsumsq) {
       epi = kEpiGeneric;
@@ -1453,6 +1464,7 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   CG_SWP(1, WM, WN, MM, 0) CG_SWP(2, WM, WN, MM, 0) CG_SWP(2, WM, WN, MM, 1)
 #define CG_SWP_LEAN(WM, WN, MM)                                              \
   CG_SWP_E(1, WM, WN, MM, 0, kEpiLrelu) CG_SWP_E(1, WM, WN, MM, 0, kEpiMaskShift) \
+  CG_SWP_E(1, WM, WN, MM, 0, kEpiLreluSsq)                                        \
   CG_SWP_E(2, WM, WN, MM, 0, kEpiLrelu) CG_SWP_E(2, WM, WN, MM, 0, kEpiMask)  \
   CG_SWP_E(2, WM, WN, MM, 1, kEpiLrelu) CG_SWP_E(2, WM, WN, MM, 1, kEpiMask)
   CG_SWP_LEAN(4, 1, 2) CG_SWP_LEAN(8, 1, 2) CG_SWP_LEAN(4, 2, 2)

@@ -505,10 +505,20 @@ def _autotune_tile(d):
   _apply_tile_choice(d, best)
 
 
+# CALCIUMGAN_STATIC_TILES="a,b,..|c,d,.." (development): the static preference
+# order of the software-pipelined tiles, plain launches | fused-LayerNorm ones
+_STATIC_ORDER = __import__('os').environ.get('CALCIUMGAN_STATIC_TILES')
+
+
 def _static_swp_choice(d):
   if not _SWP_TILES or d.CK != 32:
     return None
   order = (15, 12) if d.epilogue == _lib.EPI_LN_LRELU else (14, 13, 10)
+  if _STATIC_ORDER:
+    plain, _, ln = _STATIC_ORDER.partition('|')
+    pick = ln if d.epilogue == _lib.EPI_LN_LRELU else plain
+    if pick:
+      order = tuple(int(t) for t in pick.split(','))
   lib = _lib.load()
   saved = (d.tile, d.stage_ksteps, d.split_parity, d.ksplit)
   pick = None

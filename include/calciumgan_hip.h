@@ -91,6 +91,12 @@ int cg_tile_shape(int tile, int* rows, int* cols);
  * family (0 = cg_swconv, 1 = cg_wgrad) in launch order, returns the count
  * (negative hipError_t on failure) and disables the hook.  bench.py's roofline
  * leg is its only user. */
+/* Development switch (process-wide, like the hook below): the specialised
+ * epilogues of the 32-row software-pipelined tiles (swconv_swp.hip, kEpi*) on
+ * (1) / off (0); < 0 only queries.  Returns the previous setting.  Off by
+ * default (CALCIUMGAN_SWP_LEAN_EPI=1 turns them on at load): same results bit
+ * for bit, no faster. */
+int cg_debug_lean_epilogue(int on);
 int cg_profile_enable(int max_launches);
 int cg_profile_collect(float* ms, int* family, int capacity);
 

@@ -249,6 +249,7 @@ def test_lean_epilogues_equal_the_classic_tiles_at_full_size(tile, nB, L, Ci, Co
   the memory back-pressure of a full-size launch."""
   nets_autotune = nets._AUTOTUNE
   nets._AUTOTUNE = False
+  was = _lib.load().cg_debug_lean_epilogue(1)  # (off by default: no faster)
   try:
     gen = torch.Generator(device=H.DEV)
     gen.manual_seed(99)
@@ -298,3 +299,4 @@ def test_lean_epilogues_equal_the_classic_tiles_at_full_size(tile, nB, L, Ci, Co
         [e, side], tile)
   finally:
     nets._AUTOTUNE = nets_autotune
+    _lib.load().cg_debug_lean_epilogue(was)

@@ -90,6 +90,20 @@ ALL_TILES = ([(t, ks) for t in sorted(_lib.TILES) for ks in (2, 4)] +
              [(t, 2) for t in sorted(_lib.SWP_TILES)])
 
 
+@pytest.fixture(params=[0, 1], ids=['generic_epi', 'lean_epi'])
+def epi_mode(request):
+  """Both epilogue forms of the 32-row software-pipelined tiles: the run-time
+  one (default) and the specialised ones (cg_debug_lean_epilogue)."""
+  was = _lib.load().cg_debug_lean_epilogue(request.param)
+  yield request.param
+  _lib.load().cg_debug_lean_epilogue(was)
+
+
+def _lean_only_on(epi_mode, tile):
+  if epi_mode and tile not in (13, 14, 15):
+    pytest.skip('the specialised epilogues exist on tiles 13 / 14 / 15')
+
+
 def _force_tile(d, tile, ks, sp=0):
   """Override the autotuned choice; skip when the shape does not admit the
   tile (cg_swconv answers CG_EINVAL and launches nothing)."""
@@ -107,11 +121,12 @@ def _force_tile(d, tile, ks, sp=0):
                                               (3, 512, 32, 64, 8, 3),
                                               (3, 1024, 102, 64, 24, 2),
                                               (4, 64, 70, 40, 8, 4)])
-def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp):
+def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp, epi_mode):
   """Stride-2 forward with phase shuffle + bias + LeakyReLU on every workgroup
   tile (both MFMA shapes, 4x1 and 2x2 waves) and both weight-stage depths,
   including partial column tiles (192, 102) and several samples per tile;
   sp = 1: parity-major weights with split-parity window staging."""
+  _lean_only_on(epi_mode, tile)
   rng = np.random.RandomState(2)
   x = H.int_tensor(rng, (nB, L, Ci))
   W = H.int_tensor(rng, (k, Ci, Co), -2, 2, 0.5)
@@ -155,12 +170,13 @@ def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp):
 @pytest.mark.parametrize('tile', sorted(_lib.SWP_TILES))
 @pytest.mark.parametrize('nB,L,Ci,Co,k', [(5, 512, 102, 64, 24),
                                           (3, 128, 64, 128, 24)])
-def test_conv_fwd_row_scale(tile, nB, L, Ci, Co, k, epi):
+def test_conv_fwd_row_scale(tile, nB, L, Ci, Co, k, epi, epi_mode):
   """cg_conv_desc.row_scale: y = epi((acc + bias) * row_scale[sample]) on the
   software-pipelined tiles -- the penalty's v = coef_b * g folded into the
   tangent chain's first launch.  Power-of-two scales on small-integer data:
   bit-exact against the convolution of the pre-scaled input; the classic tiles,
   split-K and the fused LayerNorm refuse the field."""
+  _lean_only_on(epi_mode, tile)
   rng = np.random.RandomState(11)
   x = H.int_tensor(rng, (nB, L, Ci))
   W = H.int_tensor(rng, (k, Ci, Co), -2, 2, 0.5)
@@ -257,9 +273,10 @@ def test_conv_fwd_split_k(tile, ksplit, nB, L, Ci, Co, k, epi):
 @pytest.mark.parametrize('tile,ks', ALL_TILES)
 @pytest.mark.parametrize('nB,L,Ci,Co,k', [(2, 512, 102, 128, 24),
                                           (5, 128, 192, 256, 24)])
-def test_conv_dgrad_every_tile(tile, ks, nB, L, Ci, Co, k):
+def test_conv_dgrad_every_tile(tile, ks, nB, L, Ci, Co, k, epi_mode):
   """Two-phase transposed convolution (f32 out, strided rows) + the fused
   per-sample sum of squares on every tile."""
+  _lean_only_on(epi_mode, tile)
   rng = np.random.RandomState(3)
   W = H.int_tensor(rng, (k, Ci, Co), -1, 1, 0.5)
   dy = H.int_tensor(rng, (nB, L // 2, Co), -2, 2)
@@ -759,7 +776,7 @@ def test_layernorm_lrelu_fwd_bwd(rows, C):
                                                 (5, 32, 64, 128, 24, 1, 3),
                                                 (4, 512, 32, 64, 8, 4, 2),
                                                 (3, 64, 16, 40, 24, 1, 0)])
-def test_dgrad_with_fused_unshuffle(nB, L, Ci, Co, k, seg, m):
+def test_dgrad_with_fused_unshuffle(nB, L, Ci, Co, k, seg, m, epi_mode):
   """Input gradient of a strided conv whose input was phase-shuffled, with the
   shuffle adjoint + LeakyReLU' mask in the launch's epilogue
   (cg_conv_desc.out_shifts + cg_unshuffle_fixup) == the plain launch followed

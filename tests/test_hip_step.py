@@ -259,7 +259,7 @@ def test_train_tracks_oracle_over_steps():
       assert np.linalg.norm(w_h - w_o.numpy()) / mv < 0.25
 
 
-def test_single_pass_generator_matches_per_update_passes(monkeypatch):
+def test_single_pass_generator_matches_per_update_passes(monkeypatch, fixed_tiles):
   """One train() with the fake batches of all critic updates from ONE
   forward-only generator pass (the single-rank schedule) against the same call
   with one pass per update (the data-parallel schedule): same weights, same
@@ -277,6 +277,16 @@ def test_single_pass_generator_matches_per_update_passes(monkeypatch):
                  [w.copy() for w in dis.get_weights()],
                  [w.copy() for w in gen.get_weights()]))
   (la, da, ga), (lb, db, gb) = outs
+  from calciumgan_amd import nets
+  if nets.DETERMINISTIC:
+    # ordered reductions + static tiles: a sample's G(z) does not depend on the
+    # batch it is computed in (same tile, same K order), so the two schedules
+    # give the SAME BITS -- the bars below (round 3's, for the atomics' run-to-run
+    # noise and Adam's sign flips) are not needed
+    assert la == lb
+    for wa, wb in zip(da + ga, db + gb):
+      np.testing.assert_array_equal(wa, wb)
+    return
   # Run-to-run noise is part of the bar: the f32 atomics of the bias / weight
   # gradient reductions land in a different order every run, and Adam's first
   # steps move a weight by lr * sign(g), so ONE near-zero gradient element whose
@@ -315,29 +325,37 @@ def test_batch_buffer_feeds_the_graph_without_a_copy():
   assert np.isfinite([float(out[0]), float(out[1]), float(out[2])]).all()
 
 
-def test_train_dynamics_follow_f32_oracle():
+def test_train_dynamics_follow_f32_oracle(capsys, fixed_tiles):
   """Twenty train() calls (100 critic + 20 generator Adam updates) at the cfg1
   layer shapes on injected randomness, against the plain f32 oracle: the bf16
   path must stay on the oracle's trajectory.  Single-step gradients differ by
   the bf16 noise floor and Adam amplifies that early on, so the bar is on the
   trajectory, at steps 10 and 20: critic loss within 5 % (+0.15), penalty
-  within 25 % (+0.01), generator loss (a difference of large terms that crosses
-  zero in this window) within 1.0 absolute.  Measured over three runs of one
-  binary (the path is not run-to-run reproducible: f32 atomics): critic loss
-  0.1-1.9 %, penalty 4-7 % at step 10 and 3.6 / 10.6 / 14.8 % at step 20,
-  generator loss 0.01-0.30."""
+  within 15 % (+0.01), generator loss (a difference of large terms that crosses
+  zero in this window) within 1.0 absolute.  Round 3 had to raise the penalty
+  bar to 25 % -- the path was not run-to-run reproducible (f32 atomics, tiles
+  tuned per process: 3.6 / 10.6 / 14.8 % at step 20 in three runs of one
+  binary); with the ordered reductions and the static tiles of `fixed_tiles`
+  every run gives the same numbers (printed), and the bar is back at 15 %."""
   hp, gen, dis, gan, real, B = _build('mid')
   orc = O.OracleGAN(hp, gen.get_weights(), dis.get_weights(),
                     emulate_bf16=False)
+  report = []
   for step in range(20):
     rand = O.draw_randomness(hp, B, seed=1000 + step)
     got = gan.train(real, rand)
     ref = orc.train(real, rand)
     if step % 10 == 9:
       g = [float(v) for v in got[:3]]
+      report.append((step + 1, abs(g[1] - ref[1]) / abs(ref[1]),
+                     abs(g[2] - ref[2]) / abs(ref[2]), abs(g[0] - ref[0])))
       assert abs(g[1] - ref[1]) < 0.05 * abs(ref[1]) + 0.15, (step, g, ref[:3])
-      assert abs(g[2] - ref[2]) < 0.25 * abs(ref[2]) + 0.01, (step, g, ref[:3])
+      assert abs(g[2] - ref[2]) < 0.15 * abs(ref[2]) + 0.01, (step, g, ref[:3])
       assert abs(g[0] - ref[0]) < 1.0, (step, g, ref[:3])
+  with capsys.disabled():
+    for r in report:
+      print('\n  step %d: critic loss %.2f %%, penalty %.2f %% off the f32 oracle; '
+            'generator loss %.3f absolute' % (r[0], 100 * r[1], 100 * r[2], r[3]))
   assert gan.dis_optimizer.iterations == 100
 
 
@@ -423,10 +441,12 @@ def test_hip_step_against_committed_golden():
   assert gh @ gr / (np.linalg.norm(gh) * np.linalg.norm(gr)) > 0.985
 
 
-def test_graph_replay_matches_eager():
+def test_graph_replay_matches_eager(fixed_tiles):
   """train() replayed as a captured hipGraph (after 2 eager warm-up calls)
   follows the eager path: same random streams, same Keras-Adam step sizes
-  (device scalar), same losses / weights up to f32-atomic ordering noise."""
+  (device scalar) -- and, with the ordered reductions, the SAME BITS: losses,
+  metrics and every weight after six steps are equal, not close (round 3: 2e-2 /
+  1e-3 for the f32 atomics' ordering noise)."""
   outs = {}
   for use_graph in (False, True):
     hp, gen, dis, gan, real, B = _build('tiny')
@@ -443,6 +463,11 @@ def test_graph_replay_matches_eager():
     assert gan.gen_optimizer.iterations == 6
     outs[use_graph] = (np.array(losses), _flat(dis.get_weights()),
                        _flat(gen.get_weights()))
+  from calciumgan_amd import nets
+  if nets.DETERMINISTIC:
+    for i in range(3):
+      np.testing.assert_array_equal(outs[True][i], outs[False][i])
+    return
   np.testing.assert_allclose(outs[True][0], outs[False][0], rtol=2e-2,
                              atol=2e-3)
   for i in (1, 2):
@@ -451,7 +476,7 @@ def test_graph_replay_matches_eager():
 
 
 @pytest.mark.parametrize('use_graph', [True, False])
-def test_outputs_stay_valid_across_graph_replays(use_graph):
+def test_outputs_stay_valid_across_graph_replays(use_graph, fixed_tiles):
   """main.py keeps the tensors train() returns in lists and converts them at
   the END of an epoch (reference main.py:34-40).  With the step replayed as a
   hipGraph the launches rewrite the same device buffers every step, so train()
@@ -481,6 +506,11 @@ def test_outputs_stay_valid_across_graph_replays(use_graph):
                   _flat(gen.get_weights()))
   # the same steps, read immediately or at the end: not "the last step 8 times"
   assert np.ptp(runs[True][0][:, 0]) > 0
+  from calciumgan_amd import nets
+  if nets.DETERMINISTIC:  # two runs of one schedule: the same bits
+    for i in range(3):
+      np.testing.assert_array_equal(runs[True][i], runs[False][i])
+    return
   np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=2e-2,
                              atol=2e-3)
   for i in (1, 2):

@@ -46,7 +46,7 @@ def _mae(a, b):
   return float(np.mean(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
 
 
-def test_generated_spike_statistics_match_oracle_trained_model(capsys):
+def test_generated_spike_statistics_match_oracle_trained_model(capsys, fixed_tiles):
   from calciumgan_amd.gan.algorithms import get_algorithm
   from calciumgan_amd.gan.models import get_models
   M = _maker()
@@ -93,15 +93,13 @@ def test_generated_spike_statistics_match_oracle_trained_model(capsys):
   # the f32 oracle than 1.5x what a second f32 run with other draws is.
   assert d_fr <= 1.5 * alt_fr, (d_fr, emu_fr, alt_fr)
   assert d_cov <= 1.5 * alt_cov, (d_cov, emu_cov, alt_cov)
-  # first moments of the raw generated signals per neuron.  (Six runs of one
-  # binary: the worst neuron's mean came within 0.011-0.027 and its standard
-  # deviation within 0.001-0.022 of bars of rtol 0.05 / 0.1 + atol 0.02 -- the
-  # path is not run-to-run reproducible (f32 atomics) and 200 train() calls
-  # amplify it --, so the bars carry another 0.02.)
+  # first moments of the raw generated signals per neuron.  (Round 3 carried
+  # another 0.02 of atol here for the run-to-run spread of the f32 atomics; the
+  # ordered reductions + `fixed_tiles` make the run reproducible: back to 0.02.)
   np.testing.assert_allclose(fake.mean(axis=(0, 1)), gold['f32_fake_mean'],
-                             rtol=0.05, atol=0.04)
+                             rtol=0.05, atol=0.02)
   np.testing.assert_allclose(fake.std(axis=(0, 1)), gold['f32_fake_std'],
-                             rtol=0.1, atol=0.04)
+                             rtol=0.1, atol=0.02)
 
 
 def _trained_maker():
@@ -113,7 +111,7 @@ def _trained_maker():
   return mod
 
 
-def test_trained_models_reach_the_oracles_statistics(capsys):
+def test_trained_models_reach_the_oracles_statistics(capsys, fixed_tiles):
   """Statistical parity on CONVERGED models (north_star:
   "metrics within 2 % of the TF reference"; procedure and error measures of
   compute_dg_metrics.py:146-201).  For three seeds the HIP path is trained for
@@ -159,6 +157,13 @@ def test_trained_models_reach_the_oracles_statistics(capsys):
     fake = fake.detach().cpu().numpy() if torch.is_tensor(fake) else np.asarray(fake)
     fr, cov = M.statistics(fake)
     hip[seed] = (fr, cov)
+    # population statistics over 4 096 generated segments
+    zb = T.z_big(hp)
+    fake_big = np.concatenate([
+        np.asarray(gan.generate(zb[i:i + 512], denorm=True).detach().cpu())
+        for i in range(0, T.N_GEN_BIG, 512)], 0)
+    pop_hip = T.population(*M.statistics(fake_big))
+    pop_ora = T.population(gold['seed%d_fr_big' % seed], gold['seed%d_cov_big' % seed])
     iu = np.triu_indices(M.C)
     o_fr, o_cov = gold['seed%d_fr' % seed], gold['seed%d_cov' % seed]
     rows.append(dict(
@@ -166,7 +171,8 @@ def test_trained_models_reach_the_oracles_statistics(capsys):
         hip_truth=T.errors(fr, truth_fr), ora_truth=T.errors(o_fr, truth_fr),
         hip_truth_cov=T.errors(cov[iu], truth_cov[iu]),
         ora_truth_cov=T.errors(o_cov[iu], truth_cov[iu]),
-        hip_ora=_mae(fr, o_fr), hip_ora_cov=_mae(cov[iu], o_cov[iu])))
+        hip_ora=_mae(fr, o_fr), hip_ora_cov=_mae(cov[iu], o_cov[iu]),
+        pop_hip=pop_hip, pop_ora=pop_ora))
   iu = np.triu_indices(len(truth_fr))
   pair_fr, pair_cov = [], []
   for a in range(len(seeds)):
@@ -195,6 +201,27 @@ def test_trained_models_reach_the_oracles_statistics(capsys):
           'of the mean rate; covariance MAE %s' % (
               ['%.4f' % v for v in pair_fr], ['%.1f' % pct(v) for v in pair_fr],
               ['%.4f' % v for v in pair_cov]))
+    # the least noisy reading of "within 2 %": ONE number per statistic
+    truth_pop = T.population(truth_fr, truth_cov)
+    print('  population statistics over %d generated segments (mean firing rate '
+          'over all neurons, Hz / mean upper-triangle covariance); truth %.5f / '
+          '%.6f' % ((T.N_GEN_BIG,) + truth_pop))
+    for r in rows:
+      rel = [abs(h - o) / abs(o) for h, o in zip(r['pop_hip'], r['pop_ora'])]
+      print('    seed %d  hip %.5f / %.6f   oracle %.5f / %.6f   hip vs oracle '
+            '%.1f %% / %.1f %%   vs truth: hip %.1f %% / %.1f %%, oracle %.1f %% / '
+            '%.1f %%' % ((r['seed'],) + r['pop_hip'] + r['pop_ora'] +
+                         (100 * rel[0], 100 * rel[1]) +
+                         tuple(100 * abs(r['pop_hip'][k] - truth_pop[k]) / truth_pop[k]
+                               for k in (0, 1)) +
+                         tuple(100 * abs(r['pop_ora'][k] - truth_pop[k]) / truth_pop[k]
+                               for k in (0, 1))))
+    po = [r['pop_ora'] for r in rows]
+    pair_pop = [(abs(po[a][0] - po[b][0]) / po[b][0], abs(po[a][1] - po[b][1]) / po[b][1])
+                for a in range(len(po)) for b in range(a + 1, len(po))]
+    print('    oracle seed vs oracle seed: rate %s %%, covariance %s %%' % (
+        ['%.1f' % (100 * v[0]) for v in pair_pop],
+        ['%.1f' % (100 * v[1]) for v in pair_pop]))
     v_hip = max(pct(r['hip_ora']) for r in rows)
     print('  2 %% bar of north_star: hip vs oracle %.1f %% -> %s; the reference '
           "algorithm against itself under another seed %.1f %% -> %s" % (
@@ -202,23 +229,33 @@ def test_trained_models_reach_the_oracles_statistics(capsys):
               'met' if pct(max(pair_fr)) <= 2 else 'NOT met'))
   worst_ora_truth = max(r['ora_truth'][0] for r in rows)
   worst_ora_truth_cov = max(r['ora_truth_cov'][0] for r in rows)
-  # (a) converged as well as the oracle's models.  The HIP path itself is not
-  # run-to-run reproducible (f32 atomics land in a different order every run,
-  # bf16 rounding does the rest, training amplifies it): five runs of ONE binary
-  # gave firing-rate MAEs against the truth of 0.047 / 0.063 / 0.024 / 0.055 /
-  # 0.037 Hz for seed 0 and 0.019 ... 0.046 for the other two (the oracle's three
-  # seeds: 0.036 / 0.022 / 0.029; an untrained model: 0.73), distances to the
-  # same-seed oracle of 0.018 ... 0.038 Hz (oracle seed pairs: 0.028 ... 0.037)
-  # and covariance distances of 0.0017 ... 0.0049 (pairs: 0.0031 ... 0.0032).
-  # The bars sit above that spread and a factor ~8 below an untrained model:
-  # every seed within 2.5 x the oracle's worst seed, the mean over the seeds
-  # within 2 x the oracle's mean.
+  # (a) converged as well as the oracle's models.  Round 3 needed bars of 2 - 2.5 x
+  # here: the HIP path was not run-to-run reproducible (f32 atomics, tiles tuned
+  # per process; five runs of one binary gave firing-rate MAEs against the truth
+  # of 0.024 ... 0.063 Hz for seed 0).  With the ordered reductions and the static
+  # tiles of `fixed_tiles` a build gives ONE set of numbers (printed above;
+  # round 4: 0.032 / 0.023 / 0.019 Hz against the oracle's 0.036 / 0.022 / 0.029),
+  # and the bars are back at 1.5 x: every seed within 1.5 x the oracle's worst
+  # seed, the mean over the seeds within 1.5 x the oracle's mean.
   mean_hip = float(np.mean([r['hip_truth'][0] for r in rows]))
   mean_ora = float(np.mean([r['ora_truth'][0] for r in rows]))
-  assert mean_hip <= 2.0 * mean_ora, (mean_hip, mean_ora, rows)
+  assert mean_hip <= 1.5 * mean_ora, (mean_hip, mean_ora, rows)
+  truth_pop = T.population(truth_fr, truth_cov)
+  worst_pop = [max(abs(q['pop_ora'][k] - truth_pop[k]) / truth_pop[k] for q in rows)
+               for k in (0, 1)]
   for r in rows:
-    assert r['hip_truth'][0] <= 2.5 * worst_ora_truth, r
-    assert r['hip_truth_cov'][0] <= 2.0 * worst_ora_truth_cov + 1e-3, r
-    # (b) within the reference algorithm's own seed-to-seed distance (x 2 / x 2.5)
-    assert r['hip_ora'] <= 2.0 * max(pair_fr), (r, pair_fr)
-    assert r['hip_ora_cov'] <= 2.5 * max(pair_cov) + 1e-3, (r, pair_cov)
+    assert r['hip_truth'][0] <= 1.5 * worst_ora_truth, r
+    assert r['hip_truth_cov'][0] <= 1.5 * worst_ora_truth_cov + 1e-3, r
+    # (b) within the reference algorithm's own seed-to-seed distance (x 1.5)
+    assert r['hip_ora'] <= 1.5 * max(pair_fr), (r, pair_fr)
+    assert r['hip_ora_cov'] <= 1.5 * max(pair_cov) + 1e-3, (r, pair_cov)
+    # (c) population statistics (one number each, 4 096 segments): the 2 % of
+    # north_star is not met between HIP and the same-seed oracle (2.7 - 15.8 % in
+    # rate, 11 - 27 % in covariance) -- nor between two oracle seeds (2.7 - 9.7 %,
+    # 4.5 - 11.8 %): at 2 400 steps the oracle's models still sit 5 - 14 % below
+    # the true population rate and 13 - 23 % below the true covariance, the HIP
+    # models 0.5 - 5.5 % and 1.5 - 2.8 %.  What holds, and is asserted: HIP is no
+    # further from the TRUTH than the oracle's worst seed.
+    for k in (0, 1):
+      rel = abs(r['pop_hip'][k] - truth_pop[k]) / truth_pop[k]
+      assert rel <= worst_pop[k] + 0.02, (r['seed'], k, rel, worst_pop)

@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B on one box, one tile table: bench.py under several environments in turn.
 #   tools/ab_env.sh ROUNDS "label1:VAR=VAL VAR2=VAL" "label2:..." ...
+# (the losses are printed beside the rates: an arm whose data went NaN runs at a
+# higher clock -- round 4's first "15 % faster" epilogue was one)
 # The first process tunes the tiles and saves its table; every timed run loads it
 # (CALCIUMGAN_AUTOTUNE=0), so all arms launch the same tiles.  An arm may name
 # another kernel library with CALCIUMGAN_HIP_LIB=<path>.
@@ -17,6 +19,6 @@ for r in $(seq 1 $ROUNDS); do
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=d['roofline']
-print('%-14s %8.1f samples/s %7.3f ms/step  swconv frac %.4f (%.1f us)  wgrad frac %.4f' % ('$label', d['value'], d['ms_per_step'], r['frac'], r['avg_launch_us'], r['wgrad_kernel']['frac']))"
+print('%-14s %8.1f samples/s %7.3f ms/step  swconv frac %.4f (%.1f us)  wgrad frac %.4f  losses %s' % ('$label', d['value'], d['ms_per_step'], r['frac'], r['avg_launch_us'], r['wgrad_kernel']['frac'], ' '.join('%.4g' % v for v in d['final_losses'])))"
   done
 done
