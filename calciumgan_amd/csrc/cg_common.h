@@ -56,6 +56,24 @@ bool cg_prof_next(int family, hipEvent_t* start, hipEvent_t* stop);
       hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);       \
   } while (0)
 
+// Launch-path caches are per DEVICE (hipFuncSetAttribute(MaxDynamicShared...)
+// applies to the current device only; a CU count or an occupancy answer belongs
+// to one device) and may be touched from several host threads: one atomic flag /
+// value per device id, checked and set without a lock (setting an attribute
+// twice is harmless).  ADVICE r3.
+#include <atomic>
+constexpr int kCgMaxDevices = 32;
+inline int cg_device_index() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kCgMaxDevices) d = 0;
+  return d;
+}
+struct CgPerDeviceFlag {
+  std::atomic<bool> set[kCgMaxDevices];
+  bool test() const { return set[cg_device_index()].load(std::memory_order_acquire); }
+  void mark() { set[cg_device_index()].store(true, std::memory_order_release); }
+};
+
 __device__ __forceinline__ float act2f(uint16_t v) {
 #if CG_ACT_F16
   return (float)__builtin_bit_cast(_Float16, v);

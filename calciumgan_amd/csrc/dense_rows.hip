@@ -311,13 +311,13 @@ __global__ __launch_bounds__(kWideThreads, 1) void dense_rows_wide_kernel(
 template <int KSTEPS>
 int launch_dense_wide(const DenseWideArgs& a, hipStream_t s) {
   const size_t lds = (size_t)kWideCols * (KSTEPS * 64 + 16);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static CgPerDeviceFlag attr_set;
+  if (!attr_set.test()) {
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&dense_rows_wide_kernel<KSTEPS>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.mark();
   }
   // one workgroup per CU: 256 = 8 XCDs x (32 / panels) row groups x panels
   const int per_xcd = 32 / a.panels * a.panels;

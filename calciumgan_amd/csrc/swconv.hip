@@ -998,14 +998,14 @@ template <int R, int MF, int WGN, int MT, int KS, bool UNI, bool SP = false,
 static int launch_swconv1(const ConvArgs& a, dim3 grid, size_t lds,
                           hipStream_t stream) {
   if (g_dry_run) return 0;  // this instantiation exists: the launch is valid
-  static bool attr_set = false;
-  if (!attr_set) {
+  static CgPerDeviceFlag attr_set;
+  if (!attr_set.test()) {
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
             &swconv_kernel<R, MF, WGN, MT, KS, UNI, SP, LN>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.mark();
   }
   if (g_split_prof.on) {
     // split-K launch being timed: cg_swconv holds the event pair; this kernel

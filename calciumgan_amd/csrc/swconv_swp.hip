@@ -1294,48 +1294,52 @@ swconv_swp_kernel(SwpArgs pa) {
 // (registers, LDS and the wave slots together; asked of the runtime once).
 template <int R, int WM, int WN, int MT, bool LN, bool NRW, int EPI>
 int swp_occupancy(size_t lds) {
-  static size_t known_lds = 0;
-  static int known = 0;
-  if (known == 0 || known_lds != lds) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nb,
-            reinterpret_cast<const void*>(
-                &swconv_swp_kernel<R, WM, WN, MT, LN, NRW, EPI>),
-            WM * WN * 64, lds) != hipSuccess || nb < 1)
-      nb = 1;
-    known = nb;
-    known_lds = lds;
-  }
-  return known;
+  // (per device; the LDS size of an instantiation can differ between launches:
+  // the last answer is kept with the size it was asked for, packed in one word)
+  static std::atomic<unsigned long long> known[kCgMaxDevices];
+  const int dev = cg_device_index();
+  const unsigned long long k = known[dev].load(std::memory_order_acquire);
+  if ((k >> 8) == (unsigned long long)lds + 1) return (int)(k & 0xff);
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &nb,
+          reinterpret_cast<const void*>(
+              &swconv_swp_kernel<R, WM, WN, MT, LN, NRW, EPI>),
+          WM * WN * 64, lds) != hipSuccess || nb < 1)
+    nb = 1;
+  if (nb > 255) nb = 255;
+  known[dev].store((((unsigned long long)lds + 1) << 8) | (unsigned)nb,
+                   std::memory_order_release);
+  return nb;
 }
 
 inline int swp_num_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
+  static std::atomic<int> cus[kCgMaxDevices];
+  const int dev = cg_device_index();
+  int c = cus[dev].load(std::memory_order_acquire);
+  if (c == 0) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess ||
         prop.multiProcessorCount < 1)
       return 256;
-    cus = prop.multiProcessorCount;
+    c = prop.multiProcessorCount;
+    cus[dev].store(c, std::memory_order_release);
   }
-  return cus;
+  return c;
 }
 
 template <int R, int WM, int WN, int MT, bool LN = false, bool NRW = false,
           int EPI = kEpiGeneric>
 int launch_swp(const SwpArgs& pa, unsigned gy, size_t lds, bool dry, hipStream_t s) {
   if (dry) return 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static CgPerDeviceFlag attr_set;
+  if (!attr_set.test()) {
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
             &swconv_swp_kernel<R, WM, WN, MT, LN, NRW, EPI>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.mark();
   }
   // persistent workgroups: one resident set walks all tiles (a multiple of 8
   // workgroups, so each keeps its XCD residue over its tiles)

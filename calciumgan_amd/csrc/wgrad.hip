@@ -1048,14 +1048,14 @@ inline unsigned wgrad_grid(const WgradArgs& a, int gz) {
 
 template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, int ALLT = 0>
 int launch_wgrad1(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static CgPerDeviceFlag attr_set;
+  if (!attr_set.test()) {
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
             &wgrad_kernel<R, TPW, ROWSPLIT, PIPE, TT, ALLT>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.mark();
   }
   CG_LAUNCH_PROF(CG_FAMILY_WGRAD, (wgrad_kernel<R, TPW, ROWSPLIT, PIPE, TT, ALLT>),
                  dim3(wgrad_grid(a, grid.z)), dim3(512), lds, s, a, (int)grid.z);
@@ -1248,13 +1248,13 @@ int launch_plan(const WgradPlan& p, hipStream_t s) {
 
 template <int TPW, int ALLT = 1>
 int launch_multi(const WgradMulti& m, int blocks, size_t lds, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static CgPerDeviceFlag attr_set;
+  if (!attr_set.test()) {
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&wgrad_multi_kernel<2, TPW, ALLT>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.mark();
   }
   CG_LAUNCH_PROF(CG_FAMILY_WGRAD, (wgrad_multi_kernel<2, TPW, ALLT>), dim3(blocks),
                  dim3(512), lds, s, m);

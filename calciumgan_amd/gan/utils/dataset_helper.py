@@ -8,6 +8,7 @@ dataset directory here holds an ``info.pkl`` with the reference's keys
 ``validation.npy`` dicts (what dataset/generate_dg_dataset.py writes).  Batches
 are float32 (B, L, C) in [0, 1]; the last batch of an epoch may be short
 (no drop_remainder, dataset_helper.py:173)."""
+import json
 import os
 import pickle
 from math import ceil
@@ -53,7 +54,12 @@ class LazyRows(object):
 
 class ArrayDataset(object):
   """Iterable of (signal, spike) batches; reshuffled every epoch when asked
-  (tf.data shuffle(buffer) + batch, dataset_helper.py:170-174)."""
+  (tf.data shuffle(buffer) + batch, dataset_helper.py:170-174).
+
+  With `gather_into` bound (main.py: WGAN_GP.batch_buffer) every batch of that
+  size is gathered into ONE device buffer, so the `signal` tensors this iterator
+  yields ALIAS each other: a consumer that keeps a reference across steps sees
+  the later batch (the training loop reads it within the step; clone to keep)."""
 
   def __init__(self, signals, spikes, batch_size, shuffle, seed=1234):
     self.signals, self.spikes = signals, spikes
@@ -125,13 +131,27 @@ def get_dataset_info(hparams):
 
 def cache_validation_set(hparams, validation):
   """dataset_helper.py:12-30: validation signals (denormalised) + spikes in
-  generated/validation.h5, written once."""
-  if os.path.exists(hparams.validation_cache):
-    return
+  generated/validation.h5, written once -- per (batch size, world size): the
+  cache holds exactly the samples a run validates (ragged tails dropped under
+  data parallelism), so one written by an earlier run of the same output_dir
+  with another batch / world size would pair compute_metrics' recorded and
+  generated trials wrongly.  Its geometry sits beside it and a mismatch rewrites
+  it."""
   sig = validation['signals']
   spikes = validation['spikes']
-  keep = validated_samples(len(sig), hparams.batch_size,
-                           getattr(hparams, 'world_size', 1))
+  world = getattr(hparams, 'world_size', 1)
+  keep = validated_samples(len(sig), hparams.batch_size, world)
+  meta = dict(batch_size=int(hparams.batch_size), world_size=int(world),
+              kept=int(len(keep)), total=int(len(sig)))
+  meta_file = hparams.validation_cache + '.json'
+  if os.path.exists(hparams.validation_cache):
+    try:
+      with open(meta_file) as f:
+        if json.load(f) == meta:
+          return
+    except (OSError, ValueError):
+      pass
+    os.remove(hparams.validation_cache)
   if len(keep) != len(sig):
     sig, spikes = sig[keep], spikes[keep]
   if hparams.normalize:
@@ -140,6 +160,8 @@ def cache_validation_set(hparams, validation):
       'signals': sig.astype(np.float32),
       'spikes': spikes.astype(np.int8)
   })
+  with open(meta_file, 'w') as f:
+    json.dump(meta, f)
 
 
 def validated_samples(num_samples, batch_size, world_size):

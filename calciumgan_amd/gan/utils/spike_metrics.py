@@ -65,14 +65,17 @@ def _exp_sum(a, b, tau):
 
 def van_rossum_distance(spikes1, spikes2=None, tau=1.0):
   """spike_metrics.py:41-51 -> elephant.spike_train_dissimilarity.van_rossum_dist
-  (tau = 1 s default [ext]): each train is convolved with exp(-t / tau) H(t) and
-  D[i, j]^2 = (1 / tau) int (f_i - f_j)^2 dt = 1/2 (S_ii + S_jj - 2 S_ij),
-  S_ab = sum_k sum_l exp(-|t_k - t_l| / tau)  (Houghton & Kreuz 2012: the closed
-  form Elephant evaluates; a single spike against an empty train is sqrt(1/2)).
-  Returns the full matrix, or the (spikes2 x spikes1) cross block exactly as
-  the reference slices it (result[len(spikes1):, :len(spikes2)]).  PARITY
-  UNPINNED (Elephant absent); the KL statistics compute_metrics.py builds on
-  it do not depend on the normalisation."""
+  (tau = 1 s default [ext]).  Elephant evaluates the closed form of Houghton &
+  Kreuz 2012 on the summed kernel matrix S_ab = sum_k sum_l exp(-|t_k - t_l| /
+  tau) and returns D[i, j] = sqrt(S_ii + S_jj - S_ij - S_ji) -- the
+  normalisation in which ONE spike against an empty train is at distance 1
+  (trains convolved with sqrt(2 / tau) exp(-t / tau) H(t)), without the factor
+  1/2 of the plain exp(-t / tau) kernel (round 3 carried that factor:
+  van_rossum_heatmap_min in spike_metrics.json was off by sqrt(2); the KL
+  statistics do not depend on the normalisation).  Returns the full matrix, or
+  the (spikes2 x spikes1) cross block exactly as the reference slices it
+  (result[len(spikes1):, :len(spikes2)]).  PARITY UNPINNED (Elephant absent:
+  the formula is restated from its published source, not run)."""
   spikes = np.asarray(spikes1) if spikes2 is None else np.concatenate(
       [np.asarray(spikes1), np.asarray(spikes2)], 0)
   # S = A E A^T: E the kernel between ALL spikes of the batch, A the train
@@ -85,7 +88,7 @@ def van_rossum_distance(spikes1, spikes2=None, tau=1.0):
   A = np.zeros((n, len(t)), np.float64)
   A[owner, np.arange(len(t))] = 1.0
   S = A @ E @ A.T
-  d2 = 0.5 * (np.diag(S)[:, None] + np.diag(S)[None, :] - 2.0 * S)
+  d2 = np.diag(S)[:, None] + np.diag(S)[None, :] - 2.0 * S
   result = np.sqrt(np.maximum(d2, 0.0))
   if spikes2 is not None:
     result = result[len(spikes1):, :len(spikes2)]

@@ -122,3 +122,52 @@ def test_sharded_critic_gradients_equal_global_batch():
   ref = torch.cat([g.reshape(-1) for g in res['grads']]).numpy()
   np.testing.assert_allclose(out[0], out[1], rtol=0, atol=0)
   np.testing.assert_allclose(out[0], ref, rtol=2e-4, atol=1e-7)
+
+
+def _world8_case(rank, world):
+  """cfg3's partition on eight ranks (CPU, gloo): global batch 1024 -> 8 x 128,
+  a ragged 1021-sample batch, gather of the generated shards, the shared shift
+  stream over several steps, the gradient all-reduce + scalar mean."""
+  out = {}
+  batch = torch.arange(1024 * 3, dtype=torch.float32).reshape(1024, 3)
+  mine = parallel.shard_batch(batch)
+  out['n'] = len(mine)
+  out['first'] = mine[:2, 0].tolist()
+  gathered = parallel.gather_batch(mine * 2.0)
+  out['gathered_ok'] = (None if gathered is None else
+                        bool(torch.equal(gathered, batch * 2.0)))
+  ragged = parallel.shard_batch(batch[:1021])
+  out['ragged_n'] = len(ragged)
+  g2 = parallel.gather_batch(ragged)
+  out['ragged_gathered'] = (None if g2 is None else
+                            bool(torch.equal(g2, batch[:1016])))
+  out['tiny'] = parallel.shard_batch(batch[:5]) is None
+  st = parallel.RandomStreams(1234, torch.device('cpu'), m=10)
+  out['shifts'] = [st.shifts(3).tolist() for _ in range(4)]
+  out['z0'] = st.noise(2, 4)[0].tolist()
+  sync = parallel.GradSync()
+  flat = torch.full((4110273 // 64,), float(rank))   # (a slice of the 16.4 MB buffer)
+  h = sync.all_reduce_async(flat)
+  h.wait()
+  out['grad_mean'] = float(flat[0] * sync.grad_scale)
+  out['scalars'] = sync.mean_scalars(torch.tensor([float(rank), 1.0])).tolist()
+  out['choice'] = parallel.broadcast_object((14, 2, 0, 1) if rank == 0 else None)
+  return out
+
+
+def test_world8_partition_of_cfg3():
+  """BASELINE configs[2] (8 x MI355X, global batch 1024) rehearsed on eight CPU
+  ranks: what the first RCCL run will execute around its kernels."""
+  out = _run(_world8_case, world=8)
+  assert sorted(out) == list(range(8))
+  for r in range(8):
+    o = out[r]
+    assert o['n'] == 128 and o['first'] == [3.0 * r, 3.0 * (r + 8)]
+    assert o['ragged_n'] == 127 and o['tiny']
+    assert o['gathered_ok'] is (True if r == 0 else None)
+    assert o['ragged_gathered'] is (True if r == 0 else None)
+    assert o['shifts'] == out[0]['shifts']            # one draw for all ranks
+    assert r == 0 or o['z0'] != out[0]['z0']          # private noise
+    np.testing.assert_allclose(o['grad_mean'], 3.5)   # mean of 0..7
+    np.testing.assert_allclose(o['scalars'], [3.5, 1.0])
+    assert tuple(o['choice']) == (14, 2, 0, 1)        # rank 0's tile choice

@@ -149,8 +149,9 @@ def test_oasis_solves_its_defining_problem():
 
 def test_van_rossum_and_victor_purpura_known_answers():
   """Closed forms of the two spike-train distances (spike_metrics.py:41-63 ->
-  Elephant [ext], tau = 1 s, q = 1 Hz): a lone spike against an empty train is
-  sqrt(1/2); two lone spikes dt apart sqrt(1 - exp(-dt)); identical trains 0;
+  Elephant [ext], tau = 1 s, q = 1 Hz), Elephant's normalisation: a lone spike
+  against an empty train is at distance 1 (hand-computed: S_aa = 1, S_ee = 0,
+  S_ae = 0); two lone spikes dt apart sqrt(2 (1 - exp(-dt))); identical trains 0;
   Victor-Purpura moves a spike for q dt or deletes + inserts it for 2."""
   T = 24 * 20
   a, b, c, e = (np.zeros(T, np.float32) for _ in range(4))
@@ -159,10 +160,11 @@ def test_van_rossum_and_victor_purpura_known_answers():
   c[[24, 24 * 10]] = 1 # spikes at 1 s and 10 s
   d = spike_metrics.van_rossum_distance(np.stack([a, b, c, e]))
   assert d.shape == (4, 4) and np.allclose(np.diag(d), 0)
-  np.testing.assert_allclose(d[0, 3], np.sqrt(0.5), rtol=1e-12)
-  np.testing.assert_allclose(d[0, 1], np.sqrt(1 - np.exp(-0.5)), rtol=1e-12)
+  np.testing.assert_allclose(d[0, 3], 1.0, rtol=1e-12)
+  np.testing.assert_allclose(d[0, 1], np.sqrt(2 * (1 - np.exp(-0.5))), rtol=1e-12)
   # a's spike cancels c's first one: what is left is c's lone second spike
-  np.testing.assert_allclose(d[0, 2], np.sqrt(0.5), rtol=1e-12)
+  # (S_aa = 1, S_cc = 2 + 2 e^-9, S_ac = 1 + e^-9 -> D^2 = 1)
+  np.testing.assert_allclose(d[0, 2], 1.0, rtol=1e-12)
   np.testing.assert_allclose(d, d.T)
   # the cross block is sliced as the reference slices it
   cross = spike_metrics.van_rossum_distance(np.stack([a, b]), np.stack([c, e]))
