@@ -130,6 +130,11 @@ SIGNATURES = {
                         c_f, c_vp],
     'cg_ln_lrelu_bwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                         c_vp, c_ll, c_i, c_i, c_f, c_vp, c_vp],
+    'cg_bn_stats': [c_vp, c_ll, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp],
+    'cg_bn_apply': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_f, c_f,
+                    c_vp],
+    'cg_bn_bwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i,
+                  c_i, c_f, c_f, c_i, c_vp, c_vp],
     'cg_dense1_fwd': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     'cg_dense1_bwd': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f,
                       c_vp],

@@ -331,6 +331,179 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// BatchNormalization(axis=-1) of the generator blocks (calciumgan.py:42-43;
+// Keras defaults: momentum 0.99, epsilon 1e-3, biased batch variance).  Batch
+// statistics are column sums over ALL rows: two-stage ordered reductions through
+// the shared workspace (no atomics form).
+// ---------------------------------------------------------------------------
+// per block: sum of v and of v * w over its rows for every channel, v / w chosen by
+// MODE: 0 (statistics) v = y, w = y; 1 (backward) v = do, w = xhat with
+// do = dout * (act ? lrelu'(h) : 1), xhat = (y - mean) * rstd.
+// Partial row [2][Cp] per block; thread -> (8-channel group, row lane) as colsum.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void bn_sums_kernel(
+    const uint16_t* __restrict__ y, const uint16_t* __restrict__ dout,
+    const uint16_t* __restrict__ h, const float* __restrict__ mean,
+    const float* __restrict__ var, long long rows, int C, int Cp,
+    int rows_per_block, float eps, float alpha, int act, float* __restrict__ ws) {
+  __shared__ float s1[kThreads * 8];
+  __shared__ float s2[kThreads * 8];
+  const int groups = Cp / 8;
+  const int rlanes = kThreads / groups;
+  const int grp = threadIdx.x % groups;
+  const int rl = threadIdx.x / groups;
+  float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < rlanes) {
+    float mu[8], rs[8];
+    if (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = grp * 8 + e;
+        mu[e] = c < C ? mean[c] : 0.f;
+        rs[e] = c < C ? rsqrtf(var[c] + eps) : 0.f;
+      }
+    }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    for (int rr = rl; rr < rows_per_block; rr += rlanes) {
+      const long long row = r0 + rr;
+      if (row >= rows) break;
+      float vy[8];
+      load8(y + row * Cp + grp * 8, vy);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          a1[e] += vy[e];
+          a2[e] += vy[e] * vy[e];
+        }
+      } else {
+        float vd[8], vh[8];
+        load8(dout + row * Cp + grp * 8, vd);
+        if (act) load8(h + row * Cp + grp * 8, vh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d_o = act ? vd[e] * (vh[e] > 0.f ? 1.f : alpha) : vd[e];
+          a1[e] += d_o;
+          a2[e] += d_o * ((vy[e] - mu[e]) * rs[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s1[rl * Cp + grp * 8 + e] = a1[e];
+      s2[rl * Cp + grp * 8 + e] = a2[e];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < Cp; c += kThreads) {
+    float t1 = s1[c], t2 = s2[c];
+    for (int r = 1; r < rlanes; ++r) {
+      t1 += s1[r * Cp + c];
+      t2 += s2[r * Cp + c];
+    }
+    float* row = ws + (long long)blockIdx.x * 2 * Cp;
+    row[c] = t1;
+    row[Cp + c] = t2;
+  }
+}
+
+// mean / biased variance from the partial rows (64 channels x 16 row classes per
+// block, as finish_cols_kernel) and the moving averages of the layer
+__global__ __launch_bounds__(1024) void bn_stats_finish_kernel(
+    const float* __restrict__ ws, int nparts, int C, int Cp, float inv_rows,
+    float* __restrict__ mean, float* __restrict__ var,
+    float* __restrict__ moving_mean, float* __restrict__ moving_var,
+    float momentum) {
+  __shared__ float sm[2][16][64];
+  const int lane = threadIdx.x & 63;
+  const int j = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float a = 0.f, b = 0.f;
+  if (c < Cp)
+    for (int r = j; r < nparts; r += 16) {
+      a += ws[(long long)r * 2 * Cp + c];
+      b += ws[(long long)r * 2 * Cp + Cp + c];
+    }
+  sm[0][j][lane] = a;
+  sm[1][j][lane] = b;
+  __syncthreads();
+  if (j == 0 && c < C) {
+    float t1 = sm[0][0][lane], t2 = sm[1][0][lane];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      t1 += sm[0][k][lane];
+      t2 += sm[1][k][lane];
+    }
+    const float m = t1 * inv_rows;
+    const float v = fmaxf(t2 * inv_rows - m * m, 0.f);
+    mean[c] = m;
+    var[c] = v;
+    if (moving_mean) {
+      moving_mean[c] = moving_mean[c] * momentum + m * (1.f - momentum);
+      moving_var[c] = moving_var[c] * momentum + v * (1.f - momentum);
+    }
+  }
+}
+
+// out = f((y - mean) * rsqrt(var + eps) * gamma + beta), f = max(t, alpha t)
+// (alpha = 1: no activation)
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(
+    const uint16_t* __restrict__ y, const float* __restrict__ mean,
+    const float* __restrict__ var, const float* __restrict__ gamma,
+    const float* __restrict__ beta, uint16_t* __restrict__ out, int C, int Cp,
+    float eps, float alpha, long long total8) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
+  const int per_row = Cp / 8;
+  const long long row = idx / per_row;
+  const int c0 = (int)(idx - row * per_row) * 8;
+  float v[8], o[8];
+  load8(y + row * Cp + c0, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c0 + e;
+    float t = 0.f;
+    if (c < C) {
+      t = (v[e] - mean[c]) * rsqrtf(var[c] + eps) * gamma[c] + beta[c];
+      t = fmaxf(t, alpha * t);
+    }
+    o[e] = t;
+  }
+  store8(out + row * Cp + c0, o);
+}
+
+// dy = gamma * rstd * (do - dbeta / R - xhat * dgamma / R)
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
+    const uint16_t* __restrict__ dout, const uint16_t* __restrict__ h,
+    const uint16_t* __restrict__ y, const float* __restrict__ mean,
+    const float* __restrict__ var, const float* __restrict__ gamma,
+    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+    uint16_t* __restrict__ dy, int C, int Cp, float eps, float alpha, int act,
+    float inv_rows, long long total8) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
+  const int per_row = Cp / 8;
+  const long long row = idx / per_row;
+  const int c0 = (int)(idx - row * per_row) * 8;
+  float vd[8], vh[8], vy[8], o[8];
+  load8(dout + row * Cp + c0, vd);
+  load8(y + row * Cp + c0, vy);
+  if (act) load8(h + row * Cp + c0, vh);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c0 + e;
+    float t = 0.f;
+    if (c < C) {
+      const float rs = rsqrtf(var[c] + eps);
+      const float d_o = act ? vd[e] * (vh[e] > 0.f ? 1.f : alpha) : vd[e];
+      const float xh = (vy[e] - mean[c]) * rs;
+      t = gamma[c] * rs * (d_o - dbeta[c] * inv_rows - xh * dgamma[c] * inv_rows);
+    }
+    o[e] = t;
+  }
+  store8(dy + row * Cp + c0, o);
+}
+
+// ---------------------------------------------------------------------------
 // discriminator head
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void dense1_fwd_kernel(
@@ -1100,6 +1273,78 @@ extern "C" int cg_ln_lrelu_bwd(const void* dh, const void* h, const void* y_pre,
     f.cvalid[0] = f.cvalid[1] = f.cvalid[2] = C;
     launch_finish(f, S_(stream));
   }
+  CG_LAUNCH_CHECK();
+}
+
+// rows per block of the BatchNorm column sums: partial rows [2][Cp] within the
+// workspace, at most kMaxParts blocks
+static int bn_rows_per_block(long long rows, int Cp) {
+  int rpb = 256;
+  while (rpb < 4096 && rows / (rpb * 2) >= 512) rpb *= 2;
+  while ((rows + rpb - 1) / rpb > kMaxParts ||
+         ((rows + rpb - 1) / rpb) * 2ll * Cp > kReduceWsElems)
+    rpb *= 2;
+  return rpb;
+}
+
+extern "C" int cg_bn_stats(const void* y, long long rows, int C, int Cp,
+                           float* mean, float* var, float* moving_mean,
+                           float* moving_var, float momentum, float* ws,
+                           void* stream) {
+  if (!y || !mean || !var || !ws || Cp % 8 || Cp > 2048 || C > Cp || rows < 1 ||
+      (!moving_mean != !moving_var))
+    return CG_EINVAL;
+  const int rpb = bn_rows_per_block(rows, Cp);
+  const unsigned blocks = grid1d(rows, rpb, 1LL << 31);
+  hipLaunchKernelGGL(bn_sums_kernel<0>, dim3(blocks), dim3(kThreads), 0,
+                     S_(stream), U16(y), (const uint16_t*)nullptr,
+                     (const uint16_t*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, rows, C, Cp, rpb, 0.f, 1.f, 0, ws);
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((Cp + 63) / 64), dim3(1024), 0,
+                     S_(stream), ws, (int)blocks, C, Cp, 1.f / (float)rows, mean,
+                     var, moving_mean, moving_var, momentum);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_bn_apply(const void* y, const float* mean, const float* var,
+                           const float* gamma, const float* beta, void* out,
+                           long long rows, int C, int Cp, float eps, float alpha,
+                           void* stream) {
+  if (!y || !mean || !var || !gamma || !beta || !out || Cp % 8 || C > Cp ||
+      rows < 1)
+    return CG_EINVAL;
+  const long long total8 = rows * Cp / 8;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid1d(total8, kThreads, 1LL << 31)),
+                     dim3(kThreads), 0, S_(stream), U16(y), mean, var, gamma, beta,
+                     U16W(out), C, Cp, eps, alpha, total8);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_bn_bwd(const void* dout, const void* h, const void* y,
+                         const float* mean, const float* var, const float* gamma,
+                         void* dy, float* dgamma, float* dbeta, long long rows,
+                         int C, int Cp, float eps, float alpha, int act, float* ws,
+                         void* stream) {
+  if (!dout || !y || !mean || !var || !gamma || !dy || !dgamma || !dbeta || !ws ||
+      (act && !h) || Cp % 8 || Cp > 2048 || C > Cp || rows < 1)
+    return CG_EINVAL;
+  const int rpb = bn_rows_per_block(rows, Cp);
+  const unsigned blocks = grid1d(rows, rpb, 1LL << 31);
+  hipLaunchKernelGGL(bn_sums_kernel<1>, dim3(blocks), dim3(kThreads), 0,
+                     S_(stream), U16(y), U16(dout), U16(h), mean, var, rows, C, Cp,
+                     rpb, eps, alpha, act, ws);
+  FinishArgs f;
+  f.ws = ws; f.nparts = (int)blocks; f.ncol = Cp; f.pstride = 2ll * Cp;
+  f.cstride = Cp; f.nout = 2; f.scale = 1.f;
+  f.out[0] = dbeta; f.out[1] = dgamma; f.out[2] = nullptr;
+  f.cvalid[0] = f.cvalid[1] = C; f.cvalid[2] = 0;
+  launch_finish(f, S_(stream));
+  const long long total8 = rows * Cp / 8;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel,
+                     dim3(grid1d(total8, kThreads, 1LL << 31)), dim3(kThreads), 0,
+                     S_(stream), U16(dout), U16(h), U16(y), mean, var, gamma,
+                     dgamma, dbeta, U16W(dy), C, Cp, eps, alpha, act,
+                     1.f / (float)rows, total8);
   CG_LAUNCH_CHECK();
 }
 

@@ -133,9 +133,11 @@ class WGAN_GP(GAN):
     return -fake_output.mean()
 
   def _critic_forward(self, st, real, z, alpha, shifts, slot,
-                      real_cached=False, fake=None):
+                      real_cached=False, fake=None, training=True):
     """Steps 1-5 of the critic schedule; leaves g in st['critic'].gin.  `fake`
-    is G(z) when the generator forward already ran (_critic_generate)."""
+    is G(z) when the generator forward already ran (_critic_generate).
+    training=False (validate, gan.py:87-90): BatchNormalization layers use their
+    moving statistics."""
     net_d = self.discriminator.net
     B = real.shape[0]
     lay = net_d.layers[0]
@@ -147,7 +149,7 @@ class WGAN_GP(GAN):
     plan.shifts.copy_(shifts, non_blocking=shifts.is_cuda)
     self._scale_seeds(st, 'critic', self.dis_optimizer)
     if fake is None:
-      fake = st['gws'].forward(z, keep=False)
+      fake = st['gws'].forward(z, keep=False, training=training)
     _lib.call('cg_interp_pack', nets._p(real), nets._p(fake), nets._p(alpha),
               nets._p(st['dws'].act[0]), B, lay.lin, lay.cin, lay.cin,
               self.generator.net.Cf, lay.cinp, 0 if real_cached else 1, s)
@@ -379,7 +381,9 @@ class WGAN_GP(GAN):
     if self._sync.world == 1 and not _FORCE_SPLIT:
       # no collective to cut around: the whole step is one segment (one graph)
       fns = [fn for fn, _, _ in segs]
-      if _BATCH_G and n > 1:
+      # (BatchNormalization: the batch statistics are those of ONE update's
+      # fake batch -- no batched pass)
+      if _BATCH_G and n > 1 and not self.generator.net.batch_norm:
         # ... and no all-reduce for G(z_i) to hide behind: all critic updates'
         # fake batches come from ONE generator pass at the start of the step
         def generate_all():
@@ -572,7 +576,7 @@ class WGAN_GP(GAN):
           torch.as_tensor(rand['shifts_fake'], dtype=torch.int32),
           torch.as_tensor(rand['shifts_inter'], dtype=torch.int32)
       ], dim=1)
-    fake = self._critic_forward(st, real, z, alpha, shifts, 0)
+    fake = self._critic_forward(st, real, z, alpha, shifts, 0, training=False)
     C = self.generator.net.C
     metrics = self.metrics(real, fake, fake_pitch=self.generator.net.Cf)
     loss = st['loss'][0]

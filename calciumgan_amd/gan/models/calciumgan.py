@@ -41,7 +41,10 @@ class _Model(object):
 
   @property
   def trainable_variables(self):
-    return self.net.params.views
+    """(BatchNormalization's moving statistics are weights -- get_weights() --
+    but not trainable variables, as in Keras)"""
+    p = self.net.params
+    return [v for i, v in enumerate(p.views) if i not in p.frozen]
 
   trainable_weights = trainable_variables
 
@@ -57,7 +60,7 @@ class _Model(object):
 
   def summary(self):
     print('Model: "{}"'.format(self.name))
-    for i, v in enumerate(self.trainable_variables):
+    for i, v in enumerate(self.net.params.views):
       print('  [{:02d}] {:<22} {}'.format(i, str(tuple(v.shape)),
                                           int(np.prod(v.shape))))
     print('Total params: {:,}'.format(self.count_params()))
@@ -72,7 +75,7 @@ class Generator(_Model):
     noise = torch.as_tensor(noise, dtype=torch.float32).to(
         self.net.device).contiguous()
     ws = self.net.workspace(noise.shape[0])
-    fake = ws.forward(noise)
+    fake = ws.forward(noise, training=training)
     return fake[:, :, :self.net.C].clone()
 
 

@@ -142,9 +142,8 @@ def validate_hparams(hp):
     raise ValueError('calciumgan_amd: kernel_size must be even and <= 24')
   if hp.noise_dim % 8 or hp.noise_dim < 32:
     raise ValueError('calciumgan_amd: noise_dim must be a multiple of 8, >= 32')
-  if getattr(hp, 'batch_norm', False):
-    raise ValueError('calciumgan_amd: batch_norm is not supported '
-                     '(needs cross-rank statistics under data parallelism)')
+  # (batch_norm: single rank only -- GeneratorNet raises under data parallelism,
+  # where the batch statistics would need a cross-rank reduction)
   activation_alpha(hp)  # raises for activations the kernels do not cover
   w, _ = calculate_noise_shape(hp.signal_shape, hp.noise_dim, NUM_CONVS,
                                hp.strides)

@@ -29,6 +29,8 @@ def _precision_tag():
   return 1 if _lib.active() == 'f16' else 0
 LEAKY_ALPHA = 0.3  # Keras LeakyReLU() default; gan/models/utils.py:6-8
 LN_EPS = 1e-3  # Keras LayerNormalization default epsilon
+BN_EPS = 1e-3  # Keras BatchNormalization defaults [ext]
+BN_MOMENTUM = 0.99
 
 
 def _p(t):
@@ -59,8 +61,13 @@ class FlatParams(object):
   """All parameters of one model in ONE flat f32 buffer (one Adam launch, one
   RCCL all-reduce), with per-tensor views in Keras get_weights() order."""
 
-  def __init__(self, shapes, device):
+  def __init__(self, shapes, device, frozen=()):
+    """frozen: indices of non-trainable tensors (BatchNormalization's moving
+    statistics): part of get_weights() / checkpoints, outside the parameter
+    count, and never given a gradient (Adam leaves a zero-gradient entry
+    alone)."""
     self.shapes = [tuple(s) for s in shapes]
+    self.frozen = frozenset(int(i) for i in frozen)
     sizes = [int(np.prod(s)) for s in self.shapes]
     # 16-byte align every tensor so vector loads stay aligned
     self.offsets = []
@@ -69,7 +76,7 @@ class FlatParams(object):
       self.offsets.append(off)
       off += geo.round_up(n, 4)
     self.numel = off
-    self.count = int(sum(sizes))
+    self.count = int(sum(n for i, n in enumerate(sizes) if i not in self.frozen))
     self.data = torch.zeros(off, dtype=torch.float32, device=device)
     self.grad = torch.zeros_like(self.data)
     self.m = torch.zeros_like(self.data)
@@ -949,6 +956,17 @@ class GeneratorNet(object):
     self.Cp = geo.pitch(self.C)
     self.L = hp.signal_shape[0]
     self.layer_norm = bool(hp.layer_norm)
+    # BatchNormalization before the (optional) LayerNormalization of every block
+    # (calciumgan.py:42-45); single rank only, ordered reductions only
+    self.batch_norm = bool(getattr(hp, 'batch_norm', False))
+    if self.batch_norm:
+      from . import parallel
+      if parallel.world_size() > 1:
+        raise ValueError('calciumgan_amd: batch_norm under data parallelism needs '
+                         'cross-rank batch statistics (not implemented)')
+      if not DETERMINISTIC:
+        raise ValueError('calciumgan_amd: batch_norm needs the ordered reductions '
+                         '(CALCIUMGAN_DETERMINISTIC=1, the default)')
     self.normalize = bool(hp.normalize)
     nflat = self.w0 * self.nd
     shapes = [(self.nd, nflat), (nflat,)]
@@ -956,7 +974,8 @@ class GeneratorNet(object):
         glorot_uniform(rng, (self.nd, nflat), self.nd, nflat),
         np.zeros(nflat, np.float32)
     ]
-    self.idx_conv = []
+    self.idx_conv, self.idx_bn, self.idx_ln = [], [], []
+    frozen = []
     for lay in self.layers:
       self.idx_conv.append(len(shapes))
       shapes += [(self.k, 1, lay.cout, lay.cin), (lay.cout,)]
@@ -965,6 +984,16 @@ class GeneratorNet(object):
                          self.k * lay.cout, self.k * lay.cin),
           np.zeros(lay.cout, np.float32)
       ]
+      if self.batch_norm:
+        # Keras order: gamma, beta, moving_mean, moving_variance
+        self.idx_bn.append(len(shapes))
+        frozen += [len(shapes) + 2, len(shapes) + 3]
+        shapes += [(lay.cout,)] * 4
+        init += [np.ones(lay.cout, np.float32), np.zeros(lay.cout, np.float32),
+                 np.zeros(lay.cout, np.float32), np.ones(lay.cout, np.float32)]
+      else:
+        self.idx_bn.append(None)
+      self.idx_ln.append(len(shapes) if self.layer_norm else None)
       if self.layer_norm:
         shapes += [(lay.cout,), (lay.cout,)]
         init += [np.ones(lay.cout, np.float32), np.zeros(lay.cout, np.float32)]
@@ -974,7 +1003,7 @@ class GeneratorNet(object):
         glorot_uniform(rng, (self.C, self.C), self.C, self.C),
         np.zeros(self.C, np.float32)
     ]
-    self.params = FlatParams(shapes, device)
+    self.params = FlatParams(shapes, device, frozen=frozen)
     self.params.set_weights(init)
     V = self.params.views
     # packed operands
@@ -1042,6 +1071,15 @@ class _GenWorkspace(object):
     self.mean = [None] + [z(B * l.lout, dt=torch.float32) for l in net.layers]
     self.rstd = [None] + [z(B * l.lout, dt=torch.float32) for l in net.layers]
     self.fake = z(B, net.L, net.Cf, dt=torch.float32)
+    if net.batch_norm:
+      # batch statistics of the last training-mode forward (the backward reads
+      # them) and, with a LayerNormalization behind it, the tensor between the two
+      self.bn_mean = [None] + [z(l.cout, dt=torch.float32) for l in net.layers]
+      self.bn_var = [None] + [z(l.cout, dt=torch.float32) for l in net.layers]
+      self.ybn = [None] + [z(B, l.lout, l.coutp) if net.layer_norm else None
+                           for l in net.layers]
+      if not forward_only and net.layer_norm:
+        self.dybn = [None] + [z(B, l.lout, l.coutp) for l in net.layers]
     if not forward_only:  # backward buffers
       self.dz = z(B, net.L, net.Cp)
       self.dh = [z(B, w0, nd)] + [z(B, l.lout, l.coutp) for l in net.layers]
@@ -1056,19 +1094,22 @@ class _GenWorkspace(object):
     self.ln_fused = []
     for i, (lay, ic) in enumerate(zip(net.layers, net.idx_conv)):
       op = net.w_fwd[i]
-      dst = self.ypre[i + 1] if net.layer_norm else self.h[i + 1]
-      fuse = net.layer_norm and _ln_fusable(lay, op.CK, k // 2)
+      il = net.idx_ln[i]
+      normed = net.layer_norm or net.batch_norm
+      dst = self.ypre[i + 1] if normed else self.h[i + 1]
+      fuse = (net.layer_norm and not net.batch_norm and
+              _ln_fusable(lay, op.CK, k // 2))
       self.ln_fused.append(fuse)
       self.f_conv.append(
           _conv_desc(self.h[i], op.buf, dst, B, lay.lin, lay.cinp, k // 2, 1,
                      net.fwd_offs[0], lay.lin, lay.cout, lay.lout, lay.coutp,
                      op.CK, y_stride=2, y_off=0, bias=V[ic + 1],
                      epilogue=_lib.EPI_NONE
-                     if net.layer_norm else _lib.EPI_LRELU, nphase=2,
+                     if normed else _lib.EPI_LRELU, nphase=2,
                      w_phase_stride=op.elems,
                      off_phase_step=net.fwd_offs[1] - net.fwd_offs[0],
                      yoff_phase_step=1,
-                     ln=(V[ic + 2], V[ic + 3], self.h[i + 1], self.mean[i + 1],
+                     ln=(V[il], V[il + 1], self.h[i + 1], self.mean[i + 1],
                          self.rstd[i + 1]) if fuse else None, alpha=net.alpha))
       self.f_conv_fwd_only.append(
           _conv_desc(self.h[i], op.buf, dst, B, lay.lin, lay.cinp, k // 2, 1,
@@ -1077,7 +1118,7 @@ class _GenWorkspace(object):
                      w_phase_stride=op.elems,
                      off_phase_step=net.fwd_offs[1] - net.fwd_offs[0],
                      yoff_phase_step=1,
-                     ln=(V[ic + 2], V[ic + 3], self.h[i + 1], None, None),
+                     ln=(V[il], V[il + 1], self.h[i + 1], None, None),
                      alpha=net.alpha)
           if fuse else self.f_conv[-1])
     # (fallback for outputs wider than 128 channels; the streaming Dense of
@@ -1116,11 +1157,13 @@ class _GenWorkspace(object):
     self.b_in_wgrad = _wgrad_desc(self.z, self.dy[0], G[0], B, 1, nd, 1,
                                   w0 * nd, 1, 1, 0, nd, w0 * nd, slot='in')
 
-  def forward(self, z_f32, keep=True):
+  def forward(self, z_f32, keep=True, training=True):
     """z (B, nd) f32 device -> self.fake (B, L, Cf) f32 (first C channels).
     keep=False: forward only (the fake batch of a critic update) -- the fused
     LayerNorm launches then skip the pre-activations and row statistics that
-    only backward() reads."""
+    only backward() reads.  training (BatchNormalization only): batch
+    statistics + moving-average update, as every training=True call of the
+    Keras model does; False: the moving statistics (validate / generate)."""
     net = self.net
     convs = self.f_conv if keep else self.f_conv_fwd_only
     st = _stream()
@@ -1130,10 +1173,28 @@ class _GenWorkspace(object):
     V = net.params.views
     for i, (lay, ic) in enumerate(zip(net.layers, net.idx_conv)):
       _run_conv(convs[i], st)
+      rows = self.B * lay.lout
+      ln_in = self.ypre[i + 1]
+      if net.batch_norm:
+        ib = net.idx_bn[i]
+        if training:
+          _lib.call('cg_bn_stats', _p(self.ypre[i + 1]), rows, lay.cout,
+                    lay.coutp, _p(self.bn_mean[i + 1]), _p(self.bn_var[i + 1]),
+                    _p(V[ib + 2]), _p(V[ib + 3]), BN_MOMENTUM,
+                    _p(reduce_ws(net.device)), st)
+          mean, var = self.bn_mean[i + 1], self.bn_var[i + 1]
+        else:
+          mean, var = V[ib + 2], V[ib + 3]
+        out = self.ybn[i + 1] if net.layer_norm else self.h[i + 1]
+        _lib.call('cg_bn_apply', _p(self.ypre[i + 1]), _p(mean), _p(var),
+                  _p(V[ib]), _p(V[ib + 1]), _p(out), rows, lay.cout, lay.coutp,
+                  BN_EPS, 1.0 if net.layer_norm else net.alpha, st)
+        ln_in = out
       if net.layer_norm and not self.ln_fused[i]:
-        _lib.call('cg_ln_lrelu_fwd', _p(self.ypre[i + 1]), _p(V[ic + 2]),
-                  _p(V[ic + 3]), _p(self.h[i + 1]), _p(self.mean[i + 1]),
-                  _p(self.rstd[i + 1]), self.B * lay.lout, lay.cout, lay.coutp,
+        il = net.idx_ln[i]
+        _lib.call('cg_ln_lrelu_fwd', _p(ln_in), _p(V[il]),
+                  _p(V[il + 1]), _p(self.h[i + 1]), _p(self.mean[i + 1]),
+                  _p(self.rstd[i + 1]), rows, lay.cout, lay.coutp,
                   LN_EPS, net.alpha, st)
     if net.streaming_out:
       # HBM-bound per-timestep Dense (+ sigmoid): the streaming kernel
@@ -1174,11 +1235,31 @@ class _GenWorkspace(object):
     for i in range(len(net.layers) - 1, -1, -1):
       lay, ic = net.layers[i], net.idx_conv[i]
       n = self.B * lay.lout
-      if net.layer_norm:
+      if net.batch_norm:
+        ib = net.idx_bn[i]
+        dout, hmask, act = self.dh[i + 1], self.h[i + 1], 1
+        if net.layer_norm:
+          il = net.idx_ln[i]
+          _lib.call('cg_ln_lrelu_bwd', _p(self.dh[i + 1]), _p(self.h[i + 1]),
+                    _p(self.ybn[i + 1]), _p(self.mean[i + 1]),
+                    _p(self.rstd[i + 1]), _p(V[il]), _p(self.dybn[i + 1]),
+                    _p(G[il]), _p(G[il + 1]), None, n, lay.cout, lay.coutp,
+                    net.alpha, rws, st)
+          dout, hmask, act = self.dybn[i + 1], None, 0
+        _lib.call('cg_bn_bwd', _p(dout), _p(hmask), _p(self.ypre[i + 1]),
+                  _p(self.bn_mean[i + 1]), _p(self.bn_var[i + 1]), _p(V[ib]),
+                  _p(self.dy[i + 1]), _p(G[ib]), _p(G[ib + 1]), n, lay.cout,
+                  lay.coutp, BN_EPS, net.alpha, act, rws, st)
+        # (the conv bias gradient: BatchNormalization removes the column mean, so
+        # this sum is zero up to rounding -- as the reference's autodiff gives it)
+        _lib.call('cg_colsum', _p(self.dy[i + 1]), _p(G[ic + 1]), n, lay.cout,
+                  lay.coutp, rws, st)
+      elif net.layer_norm:
+        il = net.idx_ln[i]
         _lib.call('cg_ln_lrelu_bwd', _p(self.dh[i + 1]), _p(self.h[i + 1]),
                   _p(self.ypre[i + 1]), _p(self.mean[i + 1]),
-                  _p(self.rstd[i + 1]), _p(V[ic + 2]), _p(self.dy[i + 1]),
-                  _p(G[ic + 2]), _p(G[ic + 3]), _p(G[ic + 1]), n, lay.cout,
+                  _p(self.rstd[i + 1]), _p(V[il]), _p(self.dy[i + 1]),
+                  _p(G[il]), _p(G[il + 1]), _p(G[ic + 1]), n, lay.cout,
                   lay.coutp, net.alpha, rws, st)
       else:
         _lib.call('cg_lrelu_bwd', _p(self.dh[i + 1]), _p(self.h[i + 1]),

@@ -366,6 +366,32 @@ int cg_ln_lrelu_bwd(const void* dh /*bf16*/, const void* h /*bf16*/,
                     int C, int Cp, float alpha, float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * BatchNormalization(axis=-1) of a generator block (calciumgan.py:42-43 etc.;
+ * Keras defaults: momentum 0.99, epsilon 1e-3, biased batch variance) -- single
+ * rank only (batch statistics would need a cross-rank reduction).  All three
+ * need the workspace of cg_reduce_ws_elems() floats (ordered column sums).
+ *   cg_bn_stats: mean[c] / var[c] over the rows of y; with moving_mean /
+ *     moving_var (training): moving = moving * momentum + batch * (1 - momentum).
+ *   cg_bn_apply: out = f((y - mean) * rsqrt(var + eps) * gamma + beta), f(t) =
+ *     max(t, alpha t) (alpha = 1: no activation); inference passes the moving
+ *     statistics.
+ *   cg_bn_bwd: do = dout * (act ? lrelu'(h) : 1); dbeta = sum do, dgamma = sum
+ *     do * xhat (both STORED); dy = gamma rstd (do - dbeta / R - xhat dgamma / R).
+ * y / out / dout / h / dy bf16 [rows][Cp], Cp <= 2048.
+ * ------------------------------------------------------------------------- */
+int cg_bn_stats(const void* y, long long rows, int C, int Cp, float* mean,
+                float* var, float* moving_mean /* or NULL */,
+                float* moving_var /* or NULL */, float momentum, float* ws,
+                void* stream);
+int cg_bn_apply(const void* y, const float* mean, const float* var,
+                const float* gamma, const float* beta, void* out, long long rows,
+                int C, int Cp, float eps, float alpha, void* stream);
+int cg_bn_bwd(const void* dout, const void* h /* act != 0 */, const void* y,
+              const float* mean, const float* var, const float* gamma, void* dy,
+              float* dgamma, float* dbeta, long long rows, int C, int Cp,
+              float eps, float alpha, int act, float* ws, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Discriminator head: Flatten + Dense(1) (calciumgan.py:188-190).
  * ------------------------------------------------------------------------- */
 /* h is bf16 [nB][Lt][Cp]; w is the f32 Keras kernel [Lt*C] (flatten index

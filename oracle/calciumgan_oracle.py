@@ -28,7 +28,8 @@ __all__ = [
     'conv1d_transpose_same', 'layer_norm', 'leaky_relu', 'activation_fn',
     'phase_shuffle',
     'phase_shuffle_index', 'init_generator', 'init_discriminator',
-    'count_params', 'generator_forward', 'discriminator_forward',
+    'count_params', 'generator_nontrainable', 'BN_EPS', 'BN_MOMENTUM',
+    'generator_forward', 'discriminator_forward',
     'interpolation', 'gradient_penalty', 'discriminator_loss',
     'generator_loss', 'd_step_grads', 'g_step_grads', 'keras_adam',
     'signal_metrics', 'draw_randomness', 'OracleGAN', 'bf16_round',
@@ -52,6 +53,7 @@ def make_hparams(sequence_length,
                  noise_dim=32,
                  m=2,
                  layer_norm=True,
+                 batch_norm=False,
                  normalize=True,
                  gradient_penalty=10.0,
                  n_critic=5,
@@ -72,7 +74,7 @@ def make_hparams(sequence_length,
       noise_shape=(noise_dim,),
       m=m,
       layer_norm=layer_norm,
-      batch_norm=False,
+      batch_norm=batch_norm,
       normalize=normalize,
       activation='leakyrelu',
       gradient_penalty=gradient_penalty,
@@ -293,6 +295,11 @@ def init_generator(hp, rng):
   for cout in generator_filters(hp):
     ws.append(_glorot(rng, (k, 1, cout, cin), k * cout, k * cin))
     ws.append(np.zeros(cout, np.float32))
+    if getattr(hp, 'batch_norm', False):
+      # layers.BatchNormalization(): gamma 1, beta 0, moving_mean 0,
+      # moving_variance 1 (get_weights() order) [ext]
+      ws += [np.ones(cout, np.float32), np.zeros(cout, np.float32),
+             np.zeros(cout, np.float32), np.ones(cout, np.float32)]
     if hp.layer_norm:
       ws.append(np.ones(cout, np.float32))
       ws.append(np.zeros(cout, np.float32))
@@ -325,28 +332,73 @@ def count_params(weights):
   return int(sum(int(np.prod(w.shape)) for w in weights))
 
 
+BN_EPS = 1e-3        # layers.BatchNormalization() defaults [ext]
+BN_MOMENTUM = 0.99
+
+
+def generator_nontrainable(hp):
+  """Indices (get_weights() order) of the generator's non-trainable arrays: the
+  moving mean / variance of every BatchNormalization layer."""
+  out = []
+  i = 2
+  for _ in range(NUM_CONVS):
+    i += 2
+    if getattr(hp, 'batch_norm', False):
+      out += [i + 2, i + 3]
+      i += 4
+    if hp.layer_norm:
+      i += 2
+  return out
+
+
 # ---------------------------------------------------------------------------
 # models
 # ---------------------------------------------------------------------------
-def generator_forward(weights, z, hp, q=_ident, wq=_ident):
+def generator_forward(weights, z, hp, q=_ident, wq=_ident, training=True,
+                      bn_updates=None):
   """generator -- calciumgan.py:22-103.  z (B, noise_dim) -> (B, L, C).
   q rounds stored activations, wq rounds the weight operands (bf16 emulation);
-  both identity for the plain fp32 oracle."""
+  both identity for the plain fp32 oracle.  batch_norm (calciumgan.py:42-43):
+  training = batch statistics over (B, L) per channel, biased variance;
+  bn_updates (a dict) receives {weight index: new moving statistic} -- Keras
+  updates the moving averages on every training=True call; training = False
+  normalises with the moving statistics (GAN.generate / validate)."""
   shape = calculate_noise_shape(hp.signal_shape, hp.noise_dim, NUM_CONVS,
                                 hp.strides)
   it = iter(weights)
+  pos = [0]
+
+  def take():
+    pos[0] += 1
+    return next(it)
+
   act = activation_fn(getattr(hp, 'activation', 'leakyrelu'))
-  dw, db = next(it), next(it)
+  dw, db = take(), take()
   x = q(act(q(z) @ wq(dw) + db))  # :32-33
   x = x.reshape(z.shape[0], shape[0], shape[1])  # :34
   for _ in range(NUM_CONVS):
-    cw, cb = next(it), next(it)
+    cw, cb = take(), take()
     x = q(conv1d_transpose_same(x, wq(cw), cb, hp.strides))
+    if getattr(hp, 'batch_norm', False):
+      g, b, mm, mv = take(), take(), take(), take()
+      if training:
+        mean = x.mean(dim=(0, 1))
+        var = ((x - mean)**2).mean(dim=(0, 1))
+        if bn_updates is not None:
+          bn_updates[pos[0] - 2] = (mm * BN_MOMENTUM +
+                                    mean.detach() * (1 - BN_MOMENTUM))
+          bn_updates[pos[0] - 1] = (mv * BN_MOMENTUM +
+                                    var.detach() * (1 - BN_MOMENTUM))
+      else:
+        mean, var = mm, mv
+      x = (x - mean) * torch.rsqrt(var + BN_EPS) * g + b
+      if hp.layer_norm:
+        x = q(x)  # (stored between the two normalisations)
     if hp.layer_norm:
-      g, b = next(it), next(it)
+      g, b = take(), take()
       x = layer_norm(x, g, b)
     x = q(act(x))
-  ow, ob = next(it), next(it)
+  ow, ob = take(), take()
   x = x @ wq(ow) + ob  # Dense on the last axis, :96
   if hp.normalize:
     x = torch.sigmoid(x)  # :98-99
@@ -407,8 +459,9 @@ def d_step_grads(gen_weights, dis_weights, real, z, alpha, shifts_real,
   wgan_gp.py:64-80.  Returns dict(loss, gp, grads, fake, real_out, fake_out,
   norm)."""
   dis = [w.detach().clone().requires_grad_(True) for w in dis_weights]
+  bn_updates = {}
   with torch.no_grad():
-    fake = generator_forward(gen_weights, z, hp, q, wq)
+    fake = generator_forward(gen_weights, z, hp, q, wq, bn_updates=bn_updates)
   real_out = discriminator_forward(dis, real, shifts_real, hp, q, wq)
   fake_out = discriminator_forward(dis, fake, shifts_fake, hp, q, wq)
   gp, norm, grad = gradient_penalty(dis, real, fake, alpha, shifts_inter, hp, q,
@@ -419,6 +472,7 @@ def d_step_grads(gen_weights, dis_weights, real, z, alpha, shifts_real,
       torch.zeros_like(w) if g is None else g for g, w in zip(grads, dis)
   ]
   return dict(
+      bn_updates=bn_updates,
       loss=loss.detach(),
       gp=gp.detach(),
       grads=[g.detach() for g in grads],
@@ -432,14 +486,19 @@ def d_step_grads(gen_weights, dis_weights, real, z, alpha, shifts_real,
 def g_step_grads(gen_weights, dis_weights, z, shifts, hp, q=_ident, wq=_ident):
   """_train_generator up to the optimizer update -- wgan_gp.py:22-36."""
   gen = [w.detach().clone().requires_grad_(True) for w in gen_weights]
-  fake = generator_forward(gen, z, hp, q, wq)
+  bn_updates = {}
+  fake = generator_forward(gen, z, hp, q, wq, bn_updates=bn_updates)
   fake_in = fake
   if q is not _ident:
     fake_in = fake  # D rounds its own input
   out = discriminator_forward(dis_weights, fake_in, shifts, hp, q, wq)
   loss = generator_loss(out)
-  grads = torch.autograd.grad(loss, gen)
+  # (the moving statistics of BatchNormalization take no gradient)
+  grads = torch.autograd.grad(loss, gen, allow_unused=True)
+  grads = [torch.zeros_like(w) if g is None else g for g, w in zip(grads, gen)]
+  bn_updates = {k: v.detach() for k, v in bn_updates.items()}
   return dict(
+      bn_updates=bn_updates,
       loss=loss.detach(), grads=[g.detach() for g in grads],
       fake=fake.detach(), fake_out=out.detach())
 
@@ -542,6 +601,7 @@ class OracleGAN(object):
     res = d_step_grads(self.gen, self.dis, self._t(inputs), self._t(r['z']),
                        self._t(r['alpha']), r['shifts_real'], r['shifts_fake'],
                        r['shifts_inter'], self.hp, self.q, self.wq)
+    self._apply_bn(res)  # (the forward pass ran: Keras has moved the averages)
     if self.dis_scale is not None and not self.dis_scale.update(res['grads']):
       return res  # non-finite gradients: update skipped
     self.dis_steps += 1
@@ -549,13 +609,21 @@ class OracleGAN(object):
       keras_adam(p, g, m, v, self.dis_steps, self.hp.learning_rate)
     return res
 
+  def _apply_bn(self, res):
+    for i, v in res.get('bn_updates', {}).items():
+      self.gen[i] = v.to(self.dtype)
+
   def train_generator(self, inputs, r):
     res = g_step_grads(self.gen, self.dis, self._t(r['z']), r['shifts'],
                        self.hp, self.q, self.wq)
+    self._apply_bn(res)
     if self.gen_scale is None or self.gen_scale.update(res['grads']):
       self.gen_steps += 1
-      for p, g, m, v in zip(self.gen, res['grads'], self.gen_m, self.gen_v):
-        keras_adam(p, g, m, v, self.gen_steps, self.hp.learning_rate)
+      frozen = set(generator_nontrainable(self.hp))
+      for i, (p, g, m, v) in enumerate(zip(self.gen, res['grads'], self.gen_m,
+                                           self.gen_v)):
+        if i not in frozen:
+          keras_adam(p, g, m, v, self.gen_steps, self.hp.learning_rate)
     res['metrics'] = signal_metrics(
         self._t(inputs), res['fake'], self.hp.signals_min, self.hp.signals_max,
         self.hp.normalize)
@@ -578,7 +646,8 @@ class OracleGAN(object):
   def generate(self, z, denorm=False):
     """GAN.generate -- gan.py:92-97."""
     with torch.no_grad():
-      fake = generator_forward(self.gen, self._t(z), self.hp, self.q, self.wq)
+      fake = generator_forward(self.gen, self._t(z), self.hp, self.q, self.wq,
+                               training=False)
     if denorm:
       fake = fake * (self.hp.signals_max -
                      self.hp.signals_min) + self.hp.signals_min

@@ -1082,3 +1082,80 @@ def test_wgrad_batched_equals_individual_launches():
   assert torch.equal(dws[0], dws[1])
   assert torch.equal(outs_b[0][0], outs_a[0][0])
   assert torch.equal(outs_b[1][0], outs_a[1][0])
+
+
+@pytest.mark.parametrize('rows,C,act', [(3000, 102, 1), (517, 320, 0), (64, 16, 1)])
+def test_batchnorm_fwd_bwd(rows, C, act):
+  """cg_bn_stats / cg_bn_apply / cg_bn_bwd (layers.BatchNormalization, training
+  mode: biased batch variance over the rows, eps 1e-3, moving averages with
+  momentum 0.99) against torch autograd on the same bf16-stored values; the
+  inference form (moving statistics) against the closed formula; the ordered
+  column sums repeat bit for bit."""
+  rng = np.random.RandomState(4)
+  cp = geo.pitch(C)
+  y = torch.tensor(rng.randn(1, rows, C).astype(np.float32) * 1.5 + 0.3)
+  gam = torch.tensor(rng.uniform(0.5, 1.5, C).astype(np.float32))
+  bet = torch.tensor(rng.randn(C).astype(np.float32) * 0.2)
+  dh = torch.tensor(rng.randn(1, rows, C).astype(np.float32))
+  alpha = ALPHA if act else 1.0
+  yd, dhd = H.to_pitch(y, cp), H.to_pitch(dh, cp)
+  yq = yd.float().cpu()[:, :, :C].clone().requires_grad_(True)
+  g_, b_ = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+  mean_r = yq.mean(dim=(0, 1))
+  var_r = ((yq - mean_r)**2).mean(dim=(0, 1))
+  t = (yq - mean_r) * torch.rsqrt(var_r + 1e-3) * g_ + b_
+  h_ref = torch.where(t > 0, t, alpha * t)
+  mean = torch.zeros(C, device=H.DEV)
+  var = torch.zeros(C, device=H.DEV)
+  mm = torch.full((C,), 0.25, device=H.DEV)
+  mv = torch.full((C,), 2.0, device=H.DEV)
+  ws = H.reduce_ws()
+  gd, bd = gam.to(H.DEV), bet.to(H.DEV)
+  _lib.call('cg_bn_stats', H.p(yd), rows, C, cp, H.p(mean), H.p(var), H.p(mm),
+            H.p(mv), 0.99, H.p(ws), H.stream())
+  h = torch.zeros(1, rows, cp, dtype=BF16, device=H.DEV)
+  _lib.call('cg_bn_apply', H.p(yd), H.p(mean), H.p(var), H.p(gd), H.p(bd), H.p(h),
+            rows, C, cp, 1e-3, alpha, H.stream())
+  H.sync()
+  np.testing.assert_allclose(mean.cpu().numpy(), mean_r.detach().numpy(),
+                             rtol=1e-4, atol=1e-5)
+  np.testing.assert_allclose(var.cpu().numpy(), var_r.detach().numpy(), rtol=1e-3)
+  np.testing.assert_allclose(mm.cpu().numpy(),
+                             0.25 * 0.99 + 0.01 * mean_r.detach().numpy(),
+                             rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(mv.cpu().numpy(),
+                             2.0 * 0.99 + 0.01 * var_r.detach().numpy(), rtol=1e-5)
+  np.testing.assert_allclose(h.float().cpu()[0, :, :C].numpy(),
+                             h_ref.detach()[0].numpy(), rtol=1e-2, atol=1e-2)
+  if cp > C:
+    assert float(h[:, :, C:].float().abs().max()) == 0.0
+  # backward: the mask comes from the bf16 h, as on the product path
+  dhq = dhd.float().cpu()[:, :, :C]
+  hq = h.float().cpu()[:, :, :C]
+  mask = torch.where(hq > 0, 1.0, alpha) if act else torch.ones_like(hq)
+  (t * (dhq * mask)).sum().backward()
+  dy = torch.zeros(1, rows, cp, dtype=BF16, device=H.DEV)
+  dg, db = H.out_buffers(True, C, C)
+  runs = []
+  for _ in range(2):
+    _lib.call('cg_bn_bwd', H.p(dhd), H.p(h) if act else None, H.p(yd), H.p(mean),
+              H.p(var), H.p(gd), H.p(dy), H.p(dg), H.p(db), rows, C, cp, 1e-3,
+              alpha, act, H.p(ws), H.stream())
+    H.sync()
+    runs.append((dg.clone(), db.clone(), dy.clone()))
+  for a, b in zip(*runs):
+    assert torch.equal(a, b)
+  np.testing.assert_allclose(dg.cpu().numpy(), g_.grad.numpy(), rtol=2e-3,
+                             atol=2e-3 * float(g_.grad.abs().max()))
+  np.testing.assert_allclose(db.cpu().numpy(), b_.grad.numpy(), rtol=2e-3,
+                             atol=2e-3 * float(b_.grad.abs().max()))
+  np.testing.assert_allclose(dy.float().cpu()[0, :, :C].numpy(),
+                             yq.grad[0].numpy(), rtol=2e-2, atol=2e-2)
+  # inference: the moving statistics in place of the batch's
+  out = torch.zeros(1, rows, cp, dtype=BF16, device=H.DEV)
+  _lib.call('cg_bn_apply', H.p(yd), H.p(mm), H.p(mv), H.p(gd), H.p(bd), H.p(out),
+            rows, C, cp, 1e-3, 1.0, H.stream())
+  H.sync()
+  ref = ((yq.detach() - mm.cpu()) * torch.rsqrt(mv.cpu() + 1e-3) * gam + bet)
+  np.testing.assert_allclose(out.float().cpu()[0, :, :C].numpy(), ref[0].numpy(),
+                             rtol=1e-2, atol=1e-2)

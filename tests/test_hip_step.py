@@ -635,3 +635,95 @@ def test_other_piecewise_linear_activations(activation):
   torch.cuda.synchronize()
   check(gen.net.params.grad_views, g_emu['grads'], g_f32['grads'],
         'generator ' + activation)
+
+
+@pytest.mark.parametrize('layer_norm', [False, True], ids=['bn', 'bn_ln'])
+def test_batch_norm_generator(layer_norm, fixed_tiles):
+  """--batch_norm (calciumgan.py:42-43: BatchNormalization after every transposed
+  convolution, before the optional LayerNormalization; single rank).  Weight
+  list as Keras orders it (gamma, beta, moving_mean, moving_variance per block;
+  the moving statistics are weights but not trainable); one critic update (the
+  generator runs in training mode and moves its averages), one generator update
+  and three train() calls against the oracle; validate() / generate() normalise
+  with the moving statistics."""
+  from calciumgan_amd.gan.algorithms import get_algorithm
+  from calciumgan_amd.gan.models import get_models
+  from calciumgan_amd.gan.models.utils import count_trainable_params
+  L, C, U, B = 128, 6, 8, 6
+  hp = O.make_hparams(L, C, U, kernel_size=24, m=2, layer_norm=layer_norm,
+                      batch_norm=True)
+  hp.verbose = 0
+  gen, dis = get_models(hp, None)
+  gan = get_algorithm(hp, gen, dis, None)
+  rng = np.random.RandomState(11)
+  gw = gen.get_weights()
+  ref_w = O.init_generator(hp, np.random.RandomState(0))
+  assert [w.shape for w in gw] == [w.shape for w in ref_w]
+  frozen = O.generator_nontrainable(hp)
+  assert sorted(gen.net.params.frozen) == frozen
+  assert count_trainable_params(gen) == sum(
+      int(np.prod(w.shape)) for i, w in enumerate(ref_w) if i not in frozen)
+  # move gamma / beta / biases away from their trivial initial values
+  for i, w in enumerate(gw):
+    if w.ndim == 1 and i not in frozen:
+      w += rng.randn(*w.shape).astype(np.float32) * 0.05
+  gen.set_weights(gw)
+  real = rng.uniform(0, 1, (B, L, C)).astype(np.float32)
+  r = O.draw_randomness(hp, B, seed=5)
+  # critic update: G(z) in training mode
+  rc = r['critic'][0]
+  emu = _oracle_critic(hp, gen, dis, real, rc, O.bf16_round)
+  gan.dis_optimizer.learning_rate = 0.0
+  loss, gp = gan._train_discriminator(real, rc, slot=0)
+  torch.cuda.synchronize()
+  np.testing.assert_allclose(float(gp), float(emu['gp']), rtol=2e-2, atol=1e-4)
+  np.testing.assert_allclose(float(loss), float(emu['loss']), rtol=2e-2, atol=2e-3)
+  after = gen.get_weights()
+  for i in frozen:   # the moving averages moved as Keras moves them
+    np.testing.assert_allclose(after[i], emu['bn_updates'][i].numpy(), rtol=2e-3,
+                               atol=2e-4)
+  # generator update from the same weights
+  gen.set_weights(gw)
+  gtw = [torch.tensor(w) for w in gw]
+  dtw = [torch.tensor(w) for w in dis.get_weights()]
+  zt = torch.tensor(r['gen']['z'])
+  emu_g = O.g_step_grads(gtw, dtw, zt, r['gen']['shifts'], hp, O.bf16_round,
+                         O.bf16_round)
+  f32_g = O.g_step_grads(gtw, dtw, zt, r['gen']['shifts'], hp)
+  gan.gen_optimizer.learning_rate = 0.0
+  gl, _ = gan._train_generator(real, r['gen'])
+  torch.cuda.synchronize()
+  np.testing.assert_allclose(float(gl), float(emu_g['loss']), rtol=2e-2, atol=2e-3)
+  fake = gan._get_state(B)['gws'].fake[:, :, :C].cpu().numpy()
+  np.testing.assert_allclose(fake, emu_g['fake'].numpy(), atol=6e-3)
+  gh = _flat(gen.net.params.grad_views)
+  ge = _flat([g.numpy() for g in emu_g['grads']])
+  gf = _flat([g.numpy() for g in f32_g['grads']])
+  # whole-gradient agreement: no further from f32 than 1.5 x the bf16 emulation
+  assert _rel(gh, gf) <= 1.5 * _rel(ge, gf) + 2e-2, (_rel(gh, gf), _rel(ge, gf))
+  assert gh @ ge / (np.linalg.norm(gh) * np.linalg.norm(ge)) > 0.98
+  for i in frozen:
+    assert float(gen.net.params.grad_views[i].abs().max()) == 0.0
+  # three train() calls with Adam on: losses and the averages track the oracle
+  hp2, gen2, dis2 = hp, *get_models(hp, None)
+  gen2.set_weights(gw)
+  gan2 = get_algorithm(hp2, gen2, dis2, None)
+  orc = O.OracleGAN(hp, gw, dis2.get_weights(), emulate_bf16=True)
+  for step in range(3):
+    rand = O.draw_randomness(hp, B, seed=300 + step)
+    got = gan2.train(real, rand)
+    ref = orc.train(real, rand)
+    torch.cuda.synchronize()
+    for k in range(3):
+      np.testing.assert_allclose(float(got[k]), ref[k], rtol=5e-2, atol=5e-3)
+  w_h = gen2.get_weights()
+  for i in frozen:
+    np.testing.assert_allclose(w_h[i], orc.gen[i].numpy(), rtol=1e-2, atol=1e-3)
+  # inference mode: generate() uses the moving statistics
+  z = rng.randn(4, hp.noise_dim).astype(np.float32)
+  out = gan2.generate(z)
+  ref_out = orc.generate(z)
+  np.testing.assert_allclose(np.asarray(out.detach().cpu()), ref_out.numpy(),
+                             atol=3e-2)
+  v = gan2.validate(real)
+  assert np.isfinite([float(v[1]), float(v[2]), float(v[3])]).all()
