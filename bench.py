@@ -326,6 +326,13 @@ def main():
       ab, alaunch = algorithmic_bytes_swconv(
           hp, B, batched_g=world == 1 and _w._BATCH_G and not _w._FORCE_SPLIT)
       roofline['algorithmic_hbm_bytes_per_launch'] = ab / alaunch
+      # context, not the roofline's denominator: what dense bf16 MFMA SUSTAINS on
+      # random operands under the package power cap (tools/probe/mfma_sustained.hip,
+      # profiles/r04_mfma_sustained.txt: 2.04 PFLOP/s at 2.07 GHz; `peak` is the
+      # 2.4 GHz figure the chip only holds on zero operands)
+      roofline['sustained_mfma_measured'] = dict(
+          tflops=2043.0, frac_of_it=flops / sec / 2043.0e12,
+          source='profiles/r04_mfma_sustained.txt')
       import glob
       # (measured per workload: the default one and BASELINE configs[4])
       pmcs = sorted(glob.glob(os.path.join(
