@@ -136,6 +136,9 @@ SIGNATURES = {
     'cg_bn_bwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_ll, c_i,
                   c_i, c_f, c_f, c_i, c_vp, c_vp],
     'cg_dense1_fwd': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    'cg_dense1_fwd_bwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i,
+                          c_i, c_f, c_vp],
+    'cg_gp_critic_loss': [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_f, c_i, c_f, c_vp],
     'cg_dense1_bwd': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f,
                       c_vp],
     'cg_dense1_wgrad': [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i,

@@ -506,12 +506,18 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
 // ---------------------------------------------------------------------------
 // discriminator head
 // ---------------------------------------------------------------------------
+// (delta != null: the same pass also seeds the backward chain,
+// delta[b][t][c] = coef[b / seg_size] * bf16(w[t*C+c]) * lrelu'(h[b][t][c]) --
+// cg_dense1_bwd's work without a second read of h: the seed does not depend on
+// the head's output)
 __global__ __launch_bounds__(kThreads) void dense1_fwd_kernel(
     const uint16_t* __restrict__ h, const float* __restrict__ w,
     const float* __restrict__ bias, float* __restrict__ out, int F, int C,
-    int Cp) {
+    int Cp, const float* __restrict__ coef, uint16_t* __restrict__ delta,
+    int seg_size, float alpha) {
   __shared__ float part[4];
   const int b = blockIdx.x;
+  const float cf = delta ? coef[b / seg_size] : 0.f;
   float s = 0.f;
   constexpr int kNB = 4;  // activation / weight load pairs in flight per lane
   for (int i0 = threadIdx.x * 8; i0 < F; i0 += kNB * kThreads * 8) {
@@ -529,10 +535,17 @@ __global__ __launch_bounds__(kThreads) void dense1_fwd_kernel(
     }
 #pragma unroll
     for (int k = 0; k < kNB; ++k) {
-      float v[8];
+      float v[8], o[8];
       unpack8(raw[k], v);
+      const int i = i0 + k * kThreads * 8;
+      const int ch = i - (i / Cp) * Cp;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[e] * act2f(f2act(wv[k][e]));
+      for (int e = 0; e < 8; ++e) {
+        const float wq = act2f(f2act(wv[k][e]));
+        s += v[e] * wq;
+        o[e] = (ch + e < C) ? cf * wq * (v[e] > 0.f ? 1.f : alpha) : 0.f;
+      }
+      if (delta && i < F) store8(delta + (long long)b * F + i, o);
     }
   }
   s = wave_sum(s);
@@ -1354,7 +1367,71 @@ extern "C" int cg_dense1_fwd(const void* h, const float* w, const float* bias,
   const int F = Lt * Cp;
   if (Cp % 8 || C > Cp || nB < 1) return CG_EINVAL;
   hipLaunchKernelGGL(dense1_fwd_kernel, dim3(nB), dim3(kThreads), 0, S_(stream),
-                     U16(h), w, bias, out, F, C, Cp);
+                     U16(h), w, bias, out, F, C, Cp, (const float*)nullptr,
+                     (uint16_t*)nullptr, 1, 1.f);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_dense1_fwd_bwd(const void* h, const float* w, const float* bias,
+                                 float* out, const float* coef, void* delta,
+                                 int nB, int Lt, int C, int Cp, int seg_size,
+                                 float alpha, void* stream) {
+  const int F = Lt * Cp;
+  if (Cp % 8 || C > Cp || nB < 1 || seg_size < 1 || !coef || !delta)
+    return CG_EINVAL;
+  hipLaunchKernelGGL(dense1_fwd_kernel, dim3(nB), dim3(kThreads), 0, S_(stream),
+                     U16(h), w, bias, out, F, C, Cp, coef, U16W(delta), seg_size,
+                     alpha);
+  CG_LAUNCH_CHECK();
+}
+
+// gp_finalize + critic_loss in one launch (both are single-block reductions over
+// the batch; the loss only needs the penalty this launch has just formed)
+__global__ void gp_critic_loss_kernel(float* __restrict__ norm, float* __restrict__ gp,
+                                      float* __restrict__ coef,
+                                      const float* __restrict__ d_out,
+                                      float* __restrict__ loss, int B, float scale,
+                                      int squared, float coef_mul) {
+  __shared__ float part[3][4];
+  float s = 0.f, sr = 0.f, sf = 0.f;
+  for (int b = threadIdx.x; b < B; b += kThreads) {
+    float nv = norm[b];
+    if (squared) {
+      nv = sqrtf(nv);
+      norm[b] = nv;
+    }
+    const float d = nv - 1.f;
+    s += d * d;
+    coef[b] = scale * 2.f * d / (B * nv) * coef_mul;
+    sr += d_out[b];
+    sf += d_out[B + b];
+  }
+  s = wave_sum(s);
+  sr = wave_sum(sr);
+  sf = wave_sum(sf);
+  if ((threadIdx.x & 63) == 0) {
+    part[0][threadIdx.x >> 6] = s;
+    part[1][threadIdx.x >> 6] = sr;
+    part[2][threadIdx.x >> 6] = sf;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float g = (part[0][0] + part[0][1] + part[0][2] + part[0][3]) / B;
+    const float mr = (part[1][0] + part[1][1] + part[1][2] + part[1][3]) / B;
+    const float mf = (part[2][0] + part[2][1] + part[2][2] + part[2][3]) / B;
+    gp[0] = g;
+    loss[0] = -mr + mf + scale * g;
+    loss[1] = -mf;
+  }
+}
+
+extern "C" int cg_gp_critic_loss(float* norm, float* gp, float* coef,
+                                 const float* d_out, float* loss, int B,
+                                 float penalty, int squared, float coef_mul,
+                                 void* stream) {
+  if (!norm || !gp || !coef || !d_out || !loss || B < 1) return CG_EINVAL;
+  hipLaunchKernelGGL(gp_critic_loss_kernel, dim3(1), dim3(kThreads), 0, S_(stream),
+                     norm, gp, coef, d_out, loss, B, penalty, squared, coef_mul);
   CG_LAUNCH_CHECK();
 }
 

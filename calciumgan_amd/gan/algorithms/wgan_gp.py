@@ -74,7 +74,7 @@ class WGAN_GP(GAN):
           gws=self.generator.net.workspace(B),
           dws=dws,
           critic=dws.plan(3 * B, B, 2 * B),
-          gen=dws.plan(B, B, 0),
+          gen=dws.plan(B, B, 0, want_norm=False),
           norm=torch.zeros(B, dtype=torch.float32, device=dev),
           coef_gp=torch.zeros(B, dtype=torch.float32, device=dev),
           gp=torch.zeros(max(self.n_critic, 1), dtype=torch.float32, device=dev),
@@ -153,8 +153,8 @@ class WGAN_GP(GAN):
     _lib.call('cg_interp_pack', nets._p(real), nets._p(fake), nets._p(alpha),
               nets._p(st['dws'].act[0]), B, lay.lin, lay.cin, lay.cin,
               self.generator.net.Cf, lay.cinp, 0 if real_cached else 1, s)
-    plan.forward()
-    plan.backward_chain()
+    plan.forward(seed_backward=True)
+    plan.backward_chain(seeded=True)
     n = lay.lin * lay.cinp
     if plan.sumsq is not None:  # ||g||^2 came out of the dgrad epilogue
       norm = plan.sumsq
@@ -164,14 +164,14 @@ class WGAN_GP(GAN):
       squared = 0
       _lib.call('cg_rownorm', nets._p(plan.gin), nets._p(norm), B, n,
                 nets._p(nets.reduce_ws(self.device)), s)
-    _lib.call('cg_gp_finalize', nets._p(norm), nets._p(st['gp'][slot:]),
-              nets._p(st['coef_gp']), B, self.penalty, squared, s)
+    # gp = mean((||g|| - 1)^2), v's per-sample factor and the critic loss: one
+    # launch (two single-block reductions over the batch)
+    _lib.call('cg_gp_critic_loss', nets._p(norm), nets._p(st['gp'][slot:]),
+              nets._p(st['coef_gp']), nets._p(st['dws'].d_out),
+              nets._p(st['loss'][slot]), B, self.penalty, squared, 1.0, s)
     if self.dis_optimizer.loss_scale is not None:
       st['coef_gp'].mul_(self.dis_optimizer.loss_scale)  # d(S * lambda * gp)/dg
     st['norm_out'] = norm
-    _lib.call('cg_critic_loss', nets._p(st['dws'].d_out),
-              nets._p(st['gp'][slot:]), self.penalty,
-              nets._p(st['loss'][slot]), B, s)
     return fake
 
   # -- the step, cut at the all-reduce points ---------------------------------
@@ -284,10 +284,10 @@ class WGAN_GP(GAN):
     self._scale_seeds(st, 'gen', self.gen_optimizer)
     _lib.call('cg_cast_pad', nets._p(fake), nets._p(st['dws'].act[0]),
               B * lay.lin, lay.cin, self.generator.net.Cf, lay.cinp, s)
-    plan.forward()
+    plan.forward(seed_backward=True)
     _lib.call('cg_neg_mean', nets._p(st['dws'].d_out), nets._p(st['gen_loss']),
               B, s)
-    plan.backward_chain()
+    plan.backward_chain(seeded=True)
     if not nets.DETERMINISTIC:
       net_g.params.grad.zero_()
     st['gws'].backward(plan.gin)

@@ -739,21 +739,23 @@ class _DisWorkspace(object):
     self.d_out = z(nB, dt=torch.float32)
     self._plans = {}
 
-  def plan(self, nB, seg_size, input_grad_from):
+  def plan(self, nB, seg_size, input_grad_from, want_norm=True):
     """Descriptors for a run over the first nB samples with shift segments of
     seg_size samples; the layer-1 input gradient is computed for samples
-    [input_grad_from, nB) (None = not at all)."""
-    key = (nB, seg_size, input_grad_from)
+    [input_grad_from, nB) (None = not at all).  want_norm: its per-sample sum of
+    squares (the penalty norm) is taken in the same launch -- the generator
+    update's pass does not need it."""
+    key = (nB, seg_size, input_grad_from, bool(want_norm))
     pl = self._plans.get(key)
     if pl is None:
-      pl = _DisPlan(self, nB, seg_size, input_grad_from)
+      pl = _DisPlan(self, nB, seg_size, input_grad_from, want_norm)
       self._plans[key] = pl
     return pl
 
 
 class _DisPlan(object):
 
-  def __init__(self, ws, nB, seg_size, input_grad_from):
+  def __init__(self, ws, nB, seg_size, input_grad_from, want_norm=True):
     net = ws.net
     dev = net.device
     self.ws, self.nB, self.seg_size = ws, nB, seg_size
@@ -828,7 +830,7 @@ class _DisPlan(object):
       # penalty norm fused into this launch's epilogue when a 256-row tile
       # never spans two samples; else the standalone cg_rownorm is used
       self.sumsq = None
-      if lay.lin // 2 >= 256 and (lay.lin // 2) % 256 == 0:
+      if want_norm and lay.lin // 2 >= 256 and (lay.lin // 2) % 256 == 0:
         self.sumsq = torch.zeros(nG, dtype=torch.float32, device=dev)
       self.input_grad = _conv_desc(
           ws.delta[1][input_grad_from:], op.buf, self.gin, nG, lay.lout,
@@ -876,25 +878,36 @@ class _DisPlan(object):
       self.jvp = build(False)
 
   # -- schedules ------------------------------------------------------------
-  def forward(self):
-    """act[0] (already filled) -> d_out[:nB]."""
+  def forward(self, seed_backward=False):
+    """act[0] (already filled) -> d_out[:nB].  seed_backward: the head's pass
+    over h5 also writes delta_5 = coef * w_d * lrelu'(h5) (the seed does not
+    depend on the head's output: one launch and one read of h5 instead of two);
+    backward_chain(seeded=True) then starts from it."""
     st = _stream()
     net, ws = self.ws.net, self.ws
     for d in self.fwd:
       _run_conv(d, st)
     last = net.layers[-1]
+    if seed_backward:
+      _lib.call('cg_dense1_fwd_bwd', _p(ws.act[-1]), _p(net.dense_w),
+                _p(net.dense_b), _p(ws.d_out), _p(self.coef), _p(ws.delta[-1]),
+                self.nB, last.lout, last.cout, last.coutp, self.seg_size,
+                net.alpha, st)
+      return
     _lib.call('cg_dense1_fwd', _p(ws.act[-1]), _p(net.dense_w), _p(net.dense_b),
               _p(ws.d_out), self.nB, last.lout, last.cout, last.coutp, st)
 
-  def backward_chain(self):
-    """delta[5] = coef * w_d * lrelu'(h5); then down to delta[1]; optional
-    layer-1 input gradient into self.gin (bf16)."""
+  def backward_chain(self, seeded=False):
+    """delta[5] = coef * w_d * lrelu'(h5) (unless forward(seed_backward=True)
+    wrote it); then down to delta[1]; optional layer-1 input gradient into
+    self.gin (bf16)."""
     st = _stream()
     net, ws = self.ws.net, self.ws
     last = net.layers[-1]
-    _lib.call('cg_dense1_bwd', _p(net.dense_w), _p(self.coef), _p(ws.act[-1]),
-              _p(ws.delta[-1]), self.nB, last.lout, last.cout, last.coutp,
-              self.seg_size, net.alpha, st)
+    if not seeded:
+      _lib.call('cg_dense1_bwd', _p(net.dense_w), _p(self.coef), _p(ws.act[-1]),
+                _p(ws.delta[-1]), self.nB, last.lout, last.cout, last.coutp,
+                self.seg_size, net.alpha, st)
     for i, d in self.dgrad:
       _run_conv(d, st)
       lay = net.layers[i - 1]

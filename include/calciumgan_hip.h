@@ -400,6 +400,12 @@ int cg_bn_bwd(const void* dout, const void* h /* act != 0 */, const void* y,
 int cg_dense1_fwd(const void* h, const float* w, const float* bias,
                   float* out /*[nB]*/, int nB, int Lt, int C, int Cp,
                   void* stream);
+/* cg_dense1_fwd and cg_dense1_bwd in one pass over h (the seed of the backward
+ * chain does not depend on the head's output) */
+int cg_dense1_fwd_bwd(const void* h, const float* w, const float* bias,
+                      float* out /*[nB]*/, const float* coef /*device [nseg]*/,
+                      void* delta /*bf16*/, int nB, int Lt, int C, int Cp,
+                      int seg_size, float alpha, void* stream);
 /* delta[b][t][c] = coef[b / seg_size] * bf16(w[t*C+c]) * lrelu'(h[b][t][c]) */
 int cg_dense1_bwd(const float* w, const float* coef /*device [nseg]*/,
                   const void* h, void* delta /*bf16*/, int nB, int Lt, int C,
@@ -450,6 +456,11 @@ int cg_scale_rows(const void* g, const float* coef, void* a0, int B,
  * out[1] = -mean(d_out[B:2B]) (generator_loss of the same fake batch) */
 int cg_critic_loss(const float* d_out, const float* gp, float penalty,
                    float* out, int B, void* stream);
+/* cg_gp_finalize followed by cg_critic_loss as ONE launch: coef additionally
+ * multiplied by coef_mul; loss[0] / loss[1] as cg_critic_loss's out. */
+int cg_gp_critic_loss(float* norm, float* gp, float* coef, const float* d_out,
+                      float* loss /*[2]*/, int B, float penalty, int squared,
+                      float coef_mul, void* stream);
 /* out[0] = -mean(d_out[0:B])  (wgan_gp.py:19-20) */
 int cg_neg_mean(const float* d_out, float* out, int B, void* stream);
 

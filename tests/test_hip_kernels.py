@@ -886,6 +886,13 @@ def test_discriminator_head_kernels():
   refd = cb * wq.reshape(1, Lt, C) * torch.where(h > 0, 1.0, ALPHA)
   np.testing.assert_array_equal(
       delta.float().cpu()[:, :, :C].numpy(), refd.to(BF16).float().numpy())
+  # both in one pass over h (what the step launches): the same bits
+  out2 = torch.zeros(nB, device=H.DEV)
+  delta2 = torch.full((nB, Lt, cp), 7.0, dtype=BF16, device=H.DEV)
+  _lib.call('cg_dense1_fwd_bwd', H.p(hd), H.p(wd), H.p(bd), H.p(out2), H.p(cd),
+            H.p(delta2), nB, Lt, C, cp, seg, ALPHA, H.stream())
+  H.sync()
+  assert torch.equal(out2, out) and torch.equal(delta2, delta)
   bc = torch.tensor([-0.5, 0.5, 0.0]).to(H.DEV)
   refw = (cb * h).sum(0).reshape(-1)
   for ws in (None, H.reduce_ws()):
@@ -957,6 +964,19 @@ def test_wgan_gp_elementwise_kernels():
   np.testing.assert_allclose(out.cpu().numpy(),
                              [exp0.item(), -do[B:2 * B].mean().item()],
                              rtol=1e-5)
+  # cg_gp_finalize + cg_critic_loss as the one launch the step uses: from the
+  # sums of squares (squared = 1), coef scaled by 2
+  nsq = (norm * norm).clone()
+  gp2, coef2, out2 = (torch.zeros(1, device=H.DEV), torch.zeros(B, device=H.DEV),
+                      torch.zeros(2, device=H.DEV))
+  _lib.call('cg_gp_critic_loss', H.p(nsq), H.p(gp2), H.p(coef2), H.p(d_out),
+            H.p(out2), B, 10.0, 1, 2.0, H.stream())
+  H.sync()
+  np.testing.assert_allclose(nsq.cpu().numpy(), norm.cpu().numpy(), rtol=1e-6)
+  np.testing.assert_allclose(gp2.cpu().numpy(), gp.cpu().numpy(), rtol=1e-5)
+  np.testing.assert_allclose(coef2.cpu().numpy(), 2.0 * coef.cpu().numpy(),
+                             rtol=1e-5)
+  np.testing.assert_allclose(out2.cpu().numpy(), out.cpu().numpy(), rtol=1e-5)
 
 
 def test_adam_colsum_sigmoid_lrelu_metrics():
