@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Inter-kernel gaps of the graph-replayed steps in a rocprofv3 kernel trace.
 
-  python3 tools/gap_analysis.py <dir with *_kernel_trace.csv> [first_kernel_substr]
+  python3 tools/gap_analysis.py <dir with *_kernel_trace.csv>
 
-Splits the dispatch stream into steps at every launch of `first_kernel_substr`
-(default: the first kernel of a replayed train() step, the noise draw), keeps
-the steps whose launch count equals the most common one (the graph replays) and
-reports per step: wall span, sum of kernel durations, idle time between
-consecutive kernels, and the idle time grouped by the kernel that FOLLOWS the
-gap (its launch latency / dependency wait)."""
+Splits the dispatch stream into bursts at host-side pauses, takes the burst with
+the most launches (the timed loop: graph replays run back to back), finds the
+period of its kernel-name sequence (= the launches of ONE train() step) and cuts
+the burst into steps of that length.  Reports per STEP: wall span, sum of kernel
+durations, idle time between consecutive kernels, and the idle time grouped by
+the kernel that FOLLOWS the gap (its launch latency / dependency wait)."""
 import collections, csv, glob, re, sys
 
 d = sys.argv[1]
@@ -36,11 +36,27 @@ for s, e, n in rows:
   cur.append((s, e, n))
 if cur:
   steps.append(cur)
-cnt = collections.Counter(len(s) for s in steps)
-common = max(cnt, key=lambda k: cnt[k] * k)
-sel = [s for s in steps if len(s) == common]
-print('%d bursts; %d of them with %d launches (taken as the replayed steps)' %
-      (len(steps), len(sel), common))
+bursts = steps
+big = max(bursts, key=len)
+names = [n for _, _, n in big]
+
+
+def period_of(seq):
+  """Smallest p with seq[i] == seq[i + p] for (almost) every i: one step."""
+  for p in range(8, len(seq) // 2 + 1):
+    same = sum(1 for i in range(len(seq) - p) if seq[i] == seq[i + p])
+    if same >= 0.98 * (len(seq) - p):
+      return p
+  return len(seq)
+
+
+period = period_of(names)
+# cut from the END of the burst: its head may hold the capture / warm-up launches
+n_steps = len(big) // period
+big = big[len(big) - n_steps * period:]
+sel = [big[i * period:(i + 1) * period] for i in range(n_steps)]
+print('%d bursts; the largest has %d launches = %d steps of %d launches' %
+      (len(bursts), len(names), n_steps, period))
 tot_span = tot_busy = tot_gap = 0.0
 by_next = collections.defaultdict(lambda: [0, 0.0])
 hist = collections.Counter()
