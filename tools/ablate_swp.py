@@ -11,7 +11,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'calciumgan_amd', 'csrc')
-OUT = os.path.join(ROOT, 'tools', 'probe', '_abl')
+# (ABL_OUT=tools/_ab/abl: a directory that travels to the GPU box)
+OUT = os.environ.get('ABL_OUT') or os.path.join(ROOT, 'tools', 'probe', '_abl')
 
 
 def no_loop(s):  # prologue + epilogue only
@@ -23,10 +24,22 @@ def no_loop(s):  # prologue + epilogue only
 
 
 def no_dma(s):  # no DMA issue inside the passes (stale LDS is read)
-  a = "      if (!last || s + 3 < NSTG) issue_b(s % kSwpRing);\n"
+  a = "      if (!ends || s + 3 < NSTG) issue_b(s % kSwpRing);\n"
   b = "        if (!last) {\n          // apw (1 or 2) slots of this wave per issuing stage"
   assert a in s and b in s
   s = s.replace(a, '')
+  return s.replace(b, "        if (false) {\n          // apw (1 or 2) slots of this wave per issuing stage")
+
+
+def no_dma_b(s):  # weight stages only
+  a = "      if (!ends || s + 3 < NSTG) issue_b(s % kSwpRing);\n"
+  assert a in s
+  return s.replace(a, '')
+
+
+def no_dma_a(s):  # window pieces only
+  b = "        if (!last) {\n          // apw (1 or 2) slots of this wave per issuing stage"
+  assert b in s
   return s.replace(b, "        if (false) {\n          // apw (1 or 2) slots of this wave per issuing stage")
 
 
@@ -37,12 +50,12 @@ def no_reads(s):  # no fragment reads at all (uninitialised operands)
 
 
 def no_barrier(s):
-  a = "      __builtin_amdgcn_s_barrier();\n      // ---- second half"
+  a = "      __builtin_amdgcn_s_barrier();\n      CG_TR(2);  // barrier\n"
   assert a in s
-  return s.replace(a, "      // ---- second half")
+  return s.replace(a, "")
 
 
-def no_epilogue(s):
+def no_epilogue(s):  # (anchor of the round-2 kernel: a no-op on the persistent form)
   return s.replace(
       '  // ---- epilogue: accumulators -> LDS -> whole-line row-contiguous stores ------\n',
       '  {\n    float sacc = 0.f;\n    for (int mt = 0; mt < MT; ++mt)\n'
@@ -72,6 +85,8 @@ VARIANTS = {
     'noepi': no_epilogue,
     'noloop': no_loop,
     'nodma': no_dma,
+    'nodma_a': no_dma_a,
+    'nodma_b': no_dma_b,
     'noreads': no_reads,
     'nobar': no_barrier,
     'mfmaonly': lambda s: no_barrier(no_reads(no_dma(s))),

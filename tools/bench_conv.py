@@ -20,7 +20,8 @@ from calciumgan_amd import _lib, geometry as geo, nets
 BF16 = torch.bfloat16
 
 
-def timeit(fn, iters=20):
+def timeit(fn, iters=int(os.environ.get('BENCH_ITERS', 20))):
+  # (BENCH_ITERS=8000: long enough for the power-limited clock to settle)
   fn()
   torch.cuda.synchronize()
   s = torch.cuda.Event(enable_timing=True)

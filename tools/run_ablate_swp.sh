@@ -6,6 +6,6 @@ GEOS=${GEOS:-"1 12 384 512 128 64 32 10 2 0 2 0 0|1 12 384 128 256 192 32 10 2 0
 echo "$GEOS" | tr "|" "\n" | while read geo; do
   echo "== $geo"
   for v in $VARIANTS; do
-    CALCIUMGAN_HIP_LIB=tools/probe/_abl/lib_swp_$v.so python tools/bench_conv.py conv $geo 2>&1 | grep -v amdgpu.ids | sed "s/^/$v: /"
+    CALCIUMGAN_HIP_LIB=${ABL_OUT:-tools/probe/_abl}/lib_swp_$v.so python tools/bench_conv.py conv $geo 2>&1 | grep -v amdgpu.ids | sed "s/^/$v: /"
   done
 done
