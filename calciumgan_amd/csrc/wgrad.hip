@@ -896,14 +896,20 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a, int gz) {
   wgrad_body<R, TPW, ROWSPLIT, PIPE, TT, ALLT>(a, bx, by, bz, gz CG_WTR_ARGS);
 }
 
-// Second stage of the partial-sum path: thread (block tile, slot, tid) sums its
-// float4 over the K' splits (each read one contiguous 4 KiB run per wave-instruction
-// pair) and adds the result into dw.  One thread owns an element: no atomics.
+// Second stage of the partial-sum path: an element (block tile, slot, tid) is one
+// float4 of a workgroup's accumulator image; its K' splits lie `blk_stride` apart
+// (each read one contiguous 4 KiB run per wave-instruction pair).  The splits of
+// an element are shared by `zc` threads of a block (the layers with few dW
+// elements have 64 splits: one thread walking them 4 at a time left the launch
+// latency-bound on those layers after the wide ones had finished), each with up
+// to 8 loads in flight; their sums meet in LDS and are added in chunk order.
+// One thread owns the element's dw entries: no atomics, a fixed order.
 struct ReduceItem {
   const float* part;
   float* dw;
   int gx, gy, gz, tpw, taps, Cx_real, Cg_real;
   int store;               // dw / dbias are stored, not added to
+  int zc;                  // threads per element (power of two <= 8)
   const float* bias_part;  // [gz][gy][64] or null
   float* dbias;
 };
@@ -914,6 +920,7 @@ struct ReduceArgs {
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceArgs ra) {
   const ReduceItem& it = ra.it[blockIdx.y];
+  __shared__ f32x4 red[256];
   if (it.bias_part && blockIdx.x == 0) {
     // conv bias gradient: the K' splits' column sums, in split order
     for (int c = threadIdx.x; c < it.gy * 64; c += 256) {
@@ -928,24 +935,41 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceArgs ra) {
   const int per_tile = it.tpw * 8 * 512;  // float4 per block tile
   const long long total = (long long)it.gx * it.gy * per_tile;
   const long long blk_stride = (long long)it.gx * it.gy * per_tile * 4;  // floats per split
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
-       e += (long long)gridDim.x * 256) {
+  const int zc = it.zc;
+  const int epb = 256 / zc;                 // elements per block and round
+  const int el = (int)threadIdx.x % epb;    // (consecutive lanes: consecutive float4)
+  const int zi = (int)threadIdx.x / epb;
+  const int chunk = (it.gz + zc - 1) / zc;
+  const int z0 = zi * chunk;
+  const int z1 = z0 + chunk < it.gz ? z0 + chunk : it.gz;
+  for (long long base = (long long)blockIdx.x * epb; base < total;
+       base += (long long)gridDim.x * epb) {
+    const long long e = base + el;
+    const bool live = e < total;
+    const float* p = it.part + (live ? e : 0) * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int z = z0; z < z1; z += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live && z + k < z1)
+          v[k] = *reinterpret_cast<const f32x4*>(p + (z + k) * blk_stride);
+      }
+      sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    if (zc > 1) {
+      red[threadIdx.x] = sum;
+      __syncthreads();
+      if (zi == 0)
+        for (int k = 1; k < zc; ++k) sum += red[k * epb + el];
+      __syncthreads();
+    }
+    if (!live || zi != 0) continue;
     const int tile = (int)(e / per_tile);
     const int rem = (int)(e - (long long)tile * per_tile);
     const int slot = rem >> 9;
     const int tid = rem & 511;
-    const float* p = it.part + (long long)tile * per_tile * 4 + rem * 4;
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    int z = 0;
-    for (; z + 4 <= it.gz; z += 4) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (z + 0) * blk_stride);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (z + 1) * blk_stride);
-      const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (z + 2) * blk_stride);
-      const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (z + 3) * blk_stride);
-      sum += (v0 + v1) + (v2 + v3);
-    }
-    for (; z < it.gz; ++z)
-      sum += *reinterpret_cast<const f32x4*>(p + z * blk_stride);
     const int bx = tile % it.gx, by = tile / it.gx;
     const int s = slot >> 3, mt = (slot >> 2) & 1, nt = slot & 3;
     const int wave = tid >> 6, lane = tid & 63;
@@ -1219,12 +1243,16 @@ void reduce_item(const WgradPlan& p, ReduceItem& it) {
   it.gx = p.gx; it.gy = p.gy; it.gz = p.nsplit; it.tpw = p.tpw;
   it.taps = p.a.taps; it.Cx_real = p.a.Cx_real; it.Cg_real = p.a.Cg_real;
   it.store = p.store; it.bias_part = p.a.bias_part; it.dbias = p.a.dbias;
+  // threads per element: chunks of at most 8 splits where 8 threads allow it
+  it.zc = 1;
+  while (it.zc < 8 && (it.gz + it.zc - 1) / it.zc > 8) it.zc *= 2;
 }
 
 int launch_reduce(const ReduceArgs& ra, hipStream_t s) {
   long long most = 0;
   for (int i = 0; i < ra.n; ++i) {
-    const long long t = (long long)ra.it[i].gx * ra.it[i].gy * ra.it[i].tpw * 8 * 512;
+    const long long t = (long long)ra.it[i].gx * ra.it[i].gy * ra.it[i].tpw * 8 * 512 *
+                        ra.it[i].zc;
     if (t > most) most = t;
   }
   long long bx = (most + 255) / 256;
