@@ -156,7 +156,10 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(
   const long long row0 = wave_id * (long long)rpw * rows_per_slot + slot;
   // kRB rows' loads are issued before any of them is reduced: one 16-byte load
   // per lane in flight cannot cover the HBM latency at this occupancy
-  constexpr int kRB = 4;
+#ifndef CG_LN_RB
+#define CG_LN_RB 4
+#endif
+  constexpr int kRB = CG_LN_RB;
   for (int it0 = 0; it0 < rows_per_slot; it0 += kRB) {
    uint4 raw[kRB];
 #pragma unroll
@@ -1241,7 +1244,11 @@ extern "C" int cg_ln_lrelu_fwd(const void* y_pre, const float* gamma,
   const int rpw = 64 / lpr;
   // rows per lane slot: enough waves to fill the chip (256 CUs x 32) before
   // each wave gets a longer sequential run; a multiple of the load batch
-  const int rows_per_slot = rows_per_slot_for(rows, rpw, 4, 8);
+#ifndef CG_LN_RPS_LO
+#define CG_LN_RPS_LO 4
+#define CG_LN_RPS_HI 8
+#endif
+  const int rows_per_slot = rows_per_slot_for(rows, rpw, CG_LN_RPS_LO, CG_LN_RPS_HI);
   hipLaunchKernelGGL(ln_fwd_kernel,
                      dim3(grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31)),
                      dim3(kThreads), 0, S_(stream), U16(y_pre), gamma, beta,

@@ -30,7 +30,7 @@ def timeit(fn, iters=30):
 def main():
   dev = 'cuda'
   st = nets._stream()
-  B = 128
+  B = int(os.environ.get('BENCH_B', 128))
   rws = torch.empty(_lib.load().cg_reduce_ws_elems(), device=dev)
   # generator LayerNorm layers: (rows, C, Cp)
   for L, C in ((128, 320), (256, 256), (512, 192), (1024, 128), (2048, 102)):

@@ -4,7 +4,7 @@
 # (use with CALCIUMGAN_HIP_LIB=<that path>)
 set -e
 name=$1; shift
-D=calciumgan_amd/csrc; O=/tmp/cg_$name; mkdir -p $O
+D=calciumgan_amd/csrc; O=${VARIANT_OUT:-/tmp}/cg_$name; mkdir -p $O
 for f in swconv swconv_swp wgrad pointwise dense_rows; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $D/$f.hip -o $O/$f.o &
 done
