@@ -111,8 +111,11 @@ class FlatParams(object):
 # the result: a process replays itself bit for bit (with CALCIUMGAN_AUTOTUNE=0 or
 # a loaded tile table also across processes), and no gradient buffer needs
 # zeroing.  CALCIUMGAN_DETERMINISTIC=0: the atomics (+= onto zeroed buffers).
-DETERMINISTIC = __import__('os').environ.get('CALCIUMGAN_DETERMINISTIC',
-                                              '1') != '0'
+# (CALCIUMGAN_WGRAD_PARTIALS=0 brings cg_wgrad's atomics back: they add onto
+# zeroed gradients, so it switches the whole mode off)
+DETERMINISTIC = (
+    __import__('os').environ.get('CALCIUMGAN_DETERMINISTIC', '1') != '0' and
+    __import__('os').environ.get('CALCIUMGAN_WGRAD_PARTIALS', '1') != '0')
 _REDUCE_WS = {}
 
 

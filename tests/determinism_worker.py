@@ -31,10 +31,13 @@ def main():
   rng = np.random.RandomState(7)
   real = torch.from_numpy(rng.uniform(0, 1, (B, L, C)).astype(np.float32)).cuda()
   h = hashlib.sha256()
+  first = None
   for _ in range(steps):
     out = gan.train(real)
     vals = torch.stack([out[0], out[1], out[2]] + list(out[3].values()))
     h.update(vals.cpu().numpy().tobytes())
+    if first is None:
+      first = [float(v) for v in vals.cpu()]
   torch.cuda.synchronize()
   hw = hashlib.sha256()
   for w in gen.get_weights() + dis.get_weights():
@@ -43,7 +46,7 @@ def main():
     hw.update(net.params.m.cpu().numpy().tobytes())
     hw.update(net.params.v.cpu().numpy().tobytes())
   print(json.dumps({'weights': hw.hexdigest(), 'outputs': h.hexdigest(),
-                    'last': [float(v) for v in vals.cpu()],
+                    'last': [float(v) for v in vals.cpu()], 'first': first,
                     'graph': gan._get_state(B).get('graph') is not None}))
 
 

@@ -53,3 +53,30 @@ def test_atomics_form_is_still_available_and_close():
   b = _run(10, (256, 16, 8, 32), {'CALCIUMGAN_DETERMINISTIC': '0'})
   import numpy as np
   np.testing.assert_allclose(a['last'], b['last'], rtol=5e-2, atol=5e-2)
+
+
+@pytest.mark.parametrize('knob', [
+    'CALCIUMGAN_WGRAD_PARTIALS=0', 'CALCIUMGAN_GRAPH=0', 'CALCIUMGAN_BATCH_G=0',
+    'CALCIUMGAN_FUSE_LN=0', 'CALCIUMGAN_FUSE_UNSHUFFLE=0',
+    'CALCIUMGAN_NARROW_LAST=0', 'CALCIUMGAN_FOLD_SCALE=0',
+    'CALCIUMGAN_SWP_TILES=0', 'CALCIUMGAN_WGRAD_XCD=0', 'CALCIUMGAN_SPLIT_K=0',
+    'CALCIUMGAN_SPLIT_SEGMENTS=1', 'CALCIUMGAN_SWP_LEAN_EPI=1'])
+def test_every_documented_switch_is_a_working_configuration(knob):
+  """README's switches select older / alternative forms of the same arithmetic.
+  Each must still train: the first train() call (five critic updates + one
+  generator update) at cfg2's layer shapes returns what the default returns, up to
+  rounding and -- for the switches that draw z in another order -- the noise of a
+  batch of 4; three calls stay finite.  (Round 4 found
+  CALCIUMGAN_WGRAD_PARTIALS=0 adding its atomics onto gradients the ordered mode
+  no longer zeroes: dis_loss 2651 for -178 from the second critic update on.)"""
+  import numpy as np
+  shape = (2048, 102, 16, 4)
+  name, value = knob.split('=')
+  a = _run(3, shape)
+  b = _run(3, shape, {name: value})
+  assert np.isfinite(b['last']).all(), b
+  fa, fb = np.asarray(a['first']), np.asarray(b['first'])
+  # gen_loss, dis_loss, gradient penalty
+  assert (np.abs(fb[:3] - fa[:3]) <= 0.25 * np.abs(fa[:3]) + 1.0).all(), (fa, fb)
+  # signal metrics of the generated batch
+  np.testing.assert_allclose(fb[3:], fa[3:], rtol=0.1, atol=0.02)
