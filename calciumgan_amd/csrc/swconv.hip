@@ -745,6 +745,7 @@ struct PackArgs {
   long long s_tap, s_c, s_n;
   int C_real, N_real, CK, c8, nchunks, Fp;
   long long Kpack, total;
+  int npad;          // padded column count: total / 8 / (nchunks * Fp)
   int parity_major;  // packed tap i holds tap 2i (i < taps/2) else 2(i-taps/2)+1
   int narrow_last;   // last chunk: 8 channels per tap, 16 slots per tap parity
 };
@@ -757,20 +758,22 @@ struct PackArgs {
 // then scattered, one instruction instead of eight); otherwise consecutive
 // threads follow the destination order and a thread's 8 channels are the
 // contiguous ones (s_c == 1).
-__device__ __forceinline__ void pack_group(const PackArgs& a, long long r) {
+// (32-bit index arithmetic: an operand has < 2^31 groups -- checked on the host --
+// and the 64-bit divisions were most of this kernel's instructions)
+__device__ __forceinline__ void pack_group(const PackArgs& a, unsigned r) {
   int f, cc, n;
   if (a.s_n == 1) {
-    const long long npad = a.total / 8 / ((long long)a.nchunks * a.Fp);
+    const unsigned npad = (unsigned)a.npad;
     n = (int)(r % npad);
-    const long long q = r / npad;
-    f = (int)(q % a.Fp);
-    cc = (int)(q / a.Fp);
-    r = ((long long)n * a.nchunks + cc) * a.Fp + f;
+    const unsigned q = r / npad;
+    f = (int)(q % (unsigned)a.Fp);
+    cc = (int)(q / (unsigned)a.Fp);
+    r = ((unsigned)n * (unsigned)a.nchunks + (unsigned)cc) * (unsigned)a.Fp + (unsigned)f;
   } else {
-    f = (int)(r % a.Fp);
-    const long long q = r / a.Fp;
-    cc = (int)(q % a.nchunks);
-    n = (int)(q / a.nchunks);
+    f = (int)(r % (unsigned)a.Fp);
+    const unsigned q = r / (unsigned)a.Fp;
+    cc = (int)(q % (unsigned)a.nchunks);
+    n = (int)(q / (unsigned)a.nchunks);
   }
   int tap = f / a.c8;
   int q8 = f - tap * a.c8;
@@ -797,7 +800,7 @@ __device__ __forceinline__ void pack_group(const PackArgs& a, long long r) {
     for (int e = 0; e < 8; ++e)
       if (c + e < a.C_real) v[e] = src[(long long)(c + e) * a.s_c];
   }
-  *reinterpret_cast<uint4*>(a.dst + r * 8) =
+  *reinterpret_cast<uint4*>(a.dst + (long long)r * 8) =
       make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]), pack2act(v[4], v[5]),
                  pack2act(v[6], v[7]));
 }
@@ -805,8 +808,8 @@ __device__ __forceinline__ void pack_group(const PackArgs& a, long long r) {
 constexpr int kPackBlock = 256 * 8;  // elements packed by one 256-thread block
 
 __global__ void pack_kernel(PackArgs a) {
-  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r * 8 >= a.total) return;
+  const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((long long)r * 8 >= a.total) return;
   pack_group(a, r);
 }
 
@@ -818,9 +821,8 @@ __global__ void pack_batched_kernel(const PackArgs* __restrict__ table,
                                     const int* __restrict__ first_block) {
   const int di = desc_of_block[blockIdx.x];
   const PackArgs a = table[di];
-  const long long r =
-      (long long)(blockIdx.x - first_block[di]) * blockDim.x + threadIdx.x;
-  if (r * 8 >= a.total) return;
+  const unsigned r = (blockIdx.x - (unsigned)first_block[di]) * blockDim.x + threadIdx.x;
+  if ((long long)r * 8 >= a.total) return;
   pack_group(a, r);
 }
 
@@ -923,6 +925,8 @@ static int fill_pack_args(const cg_pack_desc* d, PackArgs& a) {
   a.Fp = (d->taps * a.c8 + 15) / 16 * 16;
   a.Kpack = (long long)a.nchunks * a.Fp * 8;
   a.total = total;
+  if (total / 8 >= (1ll << 31)) return CG_EINVAL;
+  a.npad = (int)(total / 8 / ((long long)a.nchunks * a.Fp));
   return 0;
 }
 
@@ -967,20 +971,9 @@ extern "C" int cg_pack_batched(const void* dev_plan, int n, long long blocks,
 }
 
 extern "C" int cg_pack_weights(const cg_pack_desc* d, void* stream) {
-  const long long total = cg_packed_elems(d->N_real, d->taps, d->Cx, d->CK);
-  if (total < 0 || d->C_real > d->Cx || !narrow_ok(d)) return CG_EINVAL;
   PackArgs a;
-  a.src = d->src;
-  a.dst = reinterpret_cast<uint16_t*>(d->dst);
-  a.taps = d->taps; a.tap0 = d->tap0; a.tap_step = d->tap_step;
-  a.parity_major = d->parity_major;
-  a.narrow_last = d->narrow_last;
-  a.s_tap = d->s_tap; a.s_c = d->s_c; a.s_n = d->s_n;
-  a.C_real = d->C_real; a.N_real = d->N_real; a.CK = d->CK;
-  a.c8 = d->CK / 8; a.nchunks = d->Cx / d->CK;
-  a.Fp = (d->taps * a.c8 + 15) / 16 * 16;
-  a.Kpack = (long long)a.nchunks * a.Fp * 8;
-  a.total = total;
+  if (fill_pack_args(d, a)) return CG_EINVAL;
+  const long long total = a.total;
   const int threads = 256;
   const long long blocks = (total + kPackBlock - 1) / kPackBlock;
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(threads), 0,
