@@ -65,6 +65,7 @@ class ConvDesc(C.Structure):
       ('ksplit', c_i), ('split_ws', c_vp), ('split_ws_elems', c_ll),
       ('row_scale', c_vp),
       ('rowsumsq_ws', c_vp), ('rowsumsq_ws_elems', c_ll),
+      ('rowsumsq_defer', c_i),
   ]
 
 
@@ -139,6 +140,8 @@ SIGNATURES = {
     'cg_dense1_fwd_bwd': [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i,
                           c_i, c_f, c_vp],
     'cg_gp_critic_loss': [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_f, c_i, c_f, c_vp],
+    'cg_gp_loss_scale': [c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_f, c_f,
+                         c_vp, c_vp, c_ll, c_vp],
     'cg_dense1_bwd': [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f,
                       c_vp],
     'cg_dense1_wgrad': [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i,

@@ -1440,6 +1440,87 @@ extern "C" int cg_gp_critic_loss(float* norm, float* gp, float* coef,
   CG_LAUNCH_CHECK();
 }
 
+// dgp/dnorm per sample (x coef_mul), the one expression both halves of
+// gp_loss_scale_kernel use
+__device__ __forceinline__ float gp_coef(float nv, int B, float scale, float coef_mul) {
+  const float d = nv - 1.f;
+  return scale * 2.f * d / (B * nv) * coef_mul;
+}
+__device__ __forceinline__ float slot_sum(const float* __restrict__ ws, int P, int b) {
+  float s = 0.f;
+  for (int j = 0; j < P; ++j) s += ws[(long long)b * P + j];  // slot order
+  return s;
+}
+
+// rowsumsq_finish + gp_critic_loss + scale_rows in one launch: the LAST block is
+// gp_critic_loss_kernel on norms it forms from the slots; every other block
+// scales 2048 elements of g by its sample's coefficient, formed from the same
+// slots with the same expression (so the rows carry exactly coef[b]).
+__global__ __launch_bounds__(kThreads) void gp_loss_scale_kernel(
+    const float* __restrict__ ssq_ws, int P, float* __restrict__ norm,
+    float* __restrict__ gp, float* __restrict__ coef,
+    const float* __restrict__ d_out, float* __restrict__ loss, int B, float scale,
+    float coef_mul, const uint16_t* __restrict__ g, uint16_t* __restrict__ dst,
+    long long n, long long total8) {
+  if (blockIdx.x + 1 == gridDim.x) {
+    __shared__ float part[3][4];
+    float s = 0.f, sr = 0.f, sf = 0.f;
+    for (int b = threadIdx.x; b < B; b += kThreads) {
+      const float nv = sqrtf(slot_sum(ssq_ws, P, b));
+      norm[b] = nv;
+      const float d = nv - 1.f;
+      s += d * d;
+      coef[b] = gp_coef(nv, B, scale, coef_mul);
+      sr += d_out[b];
+      sf += d_out[B + b];
+    }
+    s = wave_sum(s);
+    sr = wave_sum(sr);
+    sf = wave_sum(sf);
+    if ((threadIdx.x & 63) == 0) {
+      part[0][threadIdx.x >> 6] = s;
+      part[1][threadIdx.x >> 6] = sr;
+      part[2][threadIdx.x >> 6] = sf;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float gm = (part[0][0] + part[0][1] + part[0][2] + part[0][3]) / B;
+      const float mr = (part[1][0] + part[1][1] + part[1][2] + part[1][3]) / B;
+      const float mf = (part[2][0] + part[2][1] + part[2][2] + part[2][3]) / B;
+      gp[0] = gm;
+      loss[0] = -mr + mf + scale * gm;
+      loss[1] = -mf;
+    }
+    return;
+  }
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
+  const long long i = idx * 8;
+  const int b = (int)(i / n);
+  const float c = gp_coef(sqrtf(slot_sum(ssq_ws, P, b)), B, scale, coef_mul);
+  float v[8], o[8];
+  load8(g + i, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = c * v[e];
+  store8(dst + i, o);
+}
+
+extern "C" int cg_gp_loss_scale(const float* ssq_ws, int P, float* norm, float* gp,
+                                float* coef, const float* d_out, float* loss,
+                                int B, float penalty, float coef_mul,
+                                const void* g, void* dst, long long n,
+                                void* stream) {
+  if (!ssq_ws || P < 1 || !norm || !gp || !coef || !d_out || !loss || B < 1)
+    return CG_EINVAL;
+  if ((g != nullptr) != (dst != nullptr) || (g && (n < 8 || n % 8))) return CG_EINVAL;
+  const long long total8 = g ? (long long)B * n / 8 : 0;
+  const unsigned blocks = (unsigned)((total8 + kThreads - 1) / kThreads) + 1;
+  hipLaunchKernelGGL(gp_loss_scale_kernel, dim3(blocks), dim3(kThreads), 0,
+                     S_(stream), ssq_ws, P, norm, gp, coef, d_out, loss, B, penalty,
+                     coef_mul, U16(g), U16W(dst), n, total8);
+  CG_LAUNCH_CHECK();
+}
+
 extern "C" int cg_dense1_bwd(const float* w, const float* coef, const void* h,
                              void* delta, int nB, int Lt, int C, int Cp,
                              int seg_size, float alpha, void* stream) {

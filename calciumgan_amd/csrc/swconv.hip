@@ -1211,13 +1211,14 @@ static int swconv_run(const cg_conv_desc* d, void* stream) {
   // tile); the finishing launch below adds a sample's slots in order
   a.ssq_ws = nullptr;
   a.ssq_P = 0;
+  if (d->rowsumsq_defer && !(d->rowsumsq && d->rowsumsq_ws)) return CG_EINVAL;
   if (d->rowsumsq && d->rowsumsq_ws) {
     a.ssq_P = (d->Lu / TM) * d->nphase * ((d->N + TN - 1) / TN);
     if (d->rowsumsq_ws_elems < (long long)d->nB * a.ssq_P) return CG_EINVAL;
     a.ssq_ws = d->rowsumsq_ws;
   }
   auto ssq_finish = [&](int rc) {
-    if (rc || !a.ssq_ws || g_dry_run) return rc;
+    if (rc || !a.ssq_ws || g_dry_run || d->rowsumsq_defer) return rc;
     hipLaunchKernelGGL(rowsumsq_finish_kernel, dim3((d->nB + 255) / 256), dim3(256),
                        0, (hipStream_t)stream, a.ssq_ws, a.ssq_P, d->rowsumsq,
                        d->nB);

@@ -44,6 +44,9 @@ _BATCH_G = os.environ.get('CALCIUMGAN_BATCH_G', '1') != '0'
 # data parallel, A/B only: wait for every gradient all-reduce right after it is
 # started instead of overlapping it with the next segment
 _DP_OVERLAP = os.environ.get('CALCIUMGAN_DP_OVERLAP', '1') != '0'
+# the penalty norm's finishing sum, gp / coef / critic loss and v's per-sample
+# scale as ONE launch (cg_gp_loss_scale) instead of three (A/B: =0)
+_FUSE_GP = os.environ.get('CALCIUMGAN_FUSE_GP', '1') != '0'
 _METRIC_KEYS = ('signals_metrics/min', 'signals_metrics/max',
                 'signals_metrics/mean', 'signals_metrics/std')
 # pinned staging slots for the host-drawn inputs of a graph replay: the host may
@@ -99,6 +102,10 @@ class WGAN_GP(GAN):
                     torch.tensor([1.0, 1.0, 0.0], device=dev)),
             gen=(st['gen'].coef.clone(), st['gen'].bias_coef.clone(),
                  torch.tensor([1.0], device=dev)))
+      # (fp16: the loss scale multiplies coef on the device afterwards -- three
+      # launches as before)
+      if _FUSE_GP and self.dis_optimizer.loss_scale is None:
+        st['critic'].defer_norm()
       self._state[B] = st
     return st
 
@@ -133,7 +140,7 @@ class WGAN_GP(GAN):
     return -fake_output.mean()
 
   def _critic_forward(self, st, real, z, alpha, shifts, slot,
-                      real_cached=False, fake=None, training=True):
+                      real_cached=False, fake=None, training=True, scale=None):
     """Steps 1-5 of the critic schedule; leaves g in st['critic'].gin.  `fake`
     is G(z) when the generator forward already ran (_critic_generate).
     training=False (validate, gan.py:87-90): BatchNormalization layers use their
@@ -156,6 +163,18 @@ class WGAN_GP(GAN):
     plan.forward(seed_backward=True)
     plan.backward_chain(seeded=True)
     n = lay.lin * lay.cinp
+    if plan.norm_deferred:
+      # slots of ||g||^2 -> norm, gp, coef, critic loss and (scale = (g, dst, n
+      # per sample): the caller's v = coef_b * g pass) in one launch
+      norm = plan.sumsq
+      slots, P = plan.ssq
+      g, dst, ns = scale if scale is not None else (None, None, 0)
+      _lib.call('cg_gp_loss_scale', nets._p(slots), P, nets._p(norm),
+                nets._p(st['gp'][slot:]), nets._p(st['coef_gp']),
+                nets._p(st['dws'].d_out), nets._p(st['loss'][slot]), B,
+                self.penalty, 1.0, nets._p(g), nets._p(dst), ns, s)
+      st['norm_out'] = norm
+      return fake
     if plan.sumsq is not None:  # ||g||^2 came out of the dgrad epilogue
       norm = plan.sumsq
       squared = 1
@@ -226,10 +245,7 @@ class WGAN_GP(GAN):
           torch.as_tensor(r['shifts_fake'], dtype=torch.int32),
           torch.as_tensor(r['shifts_inter'], dtype=torch.int32)
       ], dim=1)
-    self._critic_forward(st, real, None, alpha, shifts, slot, real_cached,
-                         fake=fake)
     plan = st['critic']
-    s = nets._stream()
     n = lay.lin * lay.cinp
     if plan.jvp_folds:
       # g already sits over the x^ segment of X0; v = lambda * dgp/dg = coef_b * g
@@ -237,13 +253,17 @@ class WGAN_GP(GAN):
       # the layer-1 weight gradient through delta_1's x^ segment (g (x) coef
       # delta == coef g (x) delta): a pass over 1/4 of the bytes
       d1 = st['dws'].delta[1][2 * B:3 * B]
-      _lib.call('cg_scale_rows', nets._p(d1), nets._p(st['coef_gp']), nets._p(d1),
-                B, d1[0].numel(), s)
+      scale = (d1, d1, d1[0].numel())
     else:
       # v = lambda * dgp/dg, written over the x^ segment of X0 (in place when g
       # already sits there)
-      _lib.call('cg_scale_rows', nets._p(plan.gin), nets._p(st['coef_gp']),
-                nets._p(st['dws'].act[0][2 * B:]), B, n, s)
+      scale = (plan.gin, st['dws'].act[0][2 * B:], n)
+    self._critic_forward(st, real, None, alpha, shifts, slot, real_cached,
+                         fake=fake, scale=scale)
+    s = nets._stream()
+    if not plan.norm_deferred:  # (else cg_gp_loss_scale has scaled the rows)
+      _lib.call('cg_scale_rows', nets._p(scale[0]), nets._p(st['coef_gp']),
+                nets._p(scale[1]), B, scale[2], s)
     plan.jvp_forward()
     if not nets.DETERMINISTIC:  # (the ordered reductions store every gradient)
       net_d.params.grad.zero_()

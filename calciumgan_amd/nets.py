@@ -311,6 +311,7 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
       wsq = torch.empty(need, dtype=torch.float32, device=x.device)
       d._keep = d._keep + (wsq,)
       d.rowsumsq_ws, d.rowsumsq_ws_elems = wsq.data_ptr(), need
+      d._ssq = (wsq, need // nB)  # the slots and their count per sample
   return d
 
 
@@ -842,6 +843,19 @@ class _DisPlan(object):
           w_phase_stride=op.elems,
           off_phase_step=net.dgrad_offs[1] - net.dgrad_offs[0],
           yoff_phase_step=1, rowsumsq=self.sumsq)
+    # (slots tensor, slots per sample) of the ordered penalty norm, or None
+    self.ssq = getattr(self.input_grad, '_ssq', None)
+    self.norm_deferred = False
+
+  def defer_norm(self):
+    """Leave the penalty norm's slots unsummed: the caller's cg_gp_loss_scale adds
+    them (one launch for norm, penalty, loss and v's scale).  Returns whether the
+    plan can (ordered mode with the norm fused into the input-gradient launch)."""
+    if self.ssq is None:
+      return False
+    self.input_grad.rowsumsq_defer = 1
+    self.norm_deferred = True
+    return True
 
   def build_jvp(self, seg_index, coef=None):
     """Tangent-forward chain (gradient-penalty second backward) over segment

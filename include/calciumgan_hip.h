@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 16
+#define CG_ABI_VERSION 17
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -196,6 +196,10 @@ typedef struct cg_conv_desc {
    * f32 atomic per workgroup into rowsumsq[b].  NULL: atomics (+=). */
   float* rowsumsq_ws;
   long long rowsumsq_ws_elems;
+  /* 1: leave the slots in rowsumsq_ws and do NOT launch the finishing pass --
+   * the caller's next launch adds them (cg_gp_loss_scale reads the slots
+   * itself: one launch fewer per critic update).  Needs rowsumsq_ws. */
+  int rowsumsq_defer;
 } cg_conv_desc;
 
 int cg_swconv(const cg_conv_desc* d, void* stream);
@@ -461,6 +465,16 @@ int cg_critic_loss(const float* d_out, const float* gp, float penalty,
 int cg_gp_critic_loss(float* norm, float* gp, float* coef, const float* d_out,
                       float* loss /*[2]*/, int B, float penalty, int squared,
                       float coef_mul, void* stream);
+/* The penalty's finalisation as ONE launch (wgan_gp.py:43-62): adds the slots a
+ * cg_swconv launch with rowsumsq_defer left in ssq_ws ([B][P] floats, P =
+ * cg_rowsumsq_ws_elems / nB) in slot order, norm[b] = sqrt of that, gp / coef /
+ * loss exactly as cg_gp_critic_loss(squared = 1), and -- g non-null -- dst[b] =
+ * coef[b] * g[b] for bf16 [B][n] rows (cg_scale_rows: every workgroup forms its
+ * sample's coefficient from the same slots, bit for bit the value coef[] gets). */
+int cg_gp_loss_scale(const float* ssq_ws, int P, float* norm, float* gp,
+                     float* coef, const float* d_out, float* loss /*[2]*/, int B,
+                     float penalty, float coef_mul, const void* g, void* dst,
+                     long long n, void* stream);
 /* out[0] = -mean(d_out[0:B])  (wgan_gp.py:19-20) */
 int cg_neg_mean(const float* d_out, float* out, int B, void* stream);
 

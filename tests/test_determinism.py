@@ -80,3 +80,14 @@ def test_every_documented_switch_is_a_working_configuration(knob):
   assert (np.abs(fb[:3] - fa[:3]) <= 0.25 * np.abs(fa[:3]) + 1.0).all(), (fa, fb)
   # signal metrics of the generated batch
   np.testing.assert_allclose(fb[3:], fa[3:], rtol=0.1, atol=0.02)
+
+
+def test_fused_penalty_launch_equals_the_three_launches_bit_for_bit():
+  """cg_gp_loss_scale (slot sums + gp / coef / loss + v's scale) against
+  rowsumsq_finish -> cg_gp_critic_loss -> cg_scale_rows (CALCIUMGAN_FUSE_GP=0):
+  the same arithmetic in the same order, so ten steps end on identical bits."""
+  shape = (2048, 102, 16, 4)
+  a = _run(10, shape)
+  b = _run(10, shape, {'CALCIUMGAN_FUSE_GP': '0'})
+  assert a['outputs'] == b['outputs'], (a['last'], b['last'])
+  assert a['weights'] == b['weights']

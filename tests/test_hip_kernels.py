@@ -977,6 +977,40 @@ def test_wgan_gp_elementwise_kernels():
   np.testing.assert_allclose(coef2.cpu().numpy(), 2.0 * coef.cpu().numpy(),
                              rtol=1e-5)
   np.testing.assert_allclose(out2.cpu().numpy(), out.cpu().numpy(), rtol=1e-5)
+  # ... and with the penalty norm's slot sums and v = coef_b * g in the same
+  # launch (cg_gp_loss_scale): equal, bit for bit, to slots summed in order ->
+  # cg_gp_critic_loss -> cg_scale_rows
+  P = 5
+  slots = torch.tensor(rng.rand(B, P).astype(np.float32) * 3.0).to(H.DEV)
+  ssum = torch.zeros(B, device=H.DEV)
+  for j in range(P):
+    ssum = ssum + slots[:, j]  # slot order
+  gp3, coef3, out3 = (torch.zeros(1, device=H.DEV), torch.zeros(B, device=H.DEV),
+                      torch.zeros(2, device=H.DEV))
+  nsq3 = ssum.clone()
+  _lib.call('cg_gp_critic_loss', H.p(nsq3), H.p(gp3), H.p(coef3), H.p(d_out),
+            H.p(out3), B, 10.0, 1, 1.0, H.stream())
+  a3 = torch.zeros(B, L * cp, dtype=BF16, device=H.DEV)
+  _lib.call('cg_scale_rows', H.p(gd), H.p(coef3), H.p(a3), B, L * cp, H.stream())
+  norm4, gp4, coef4, out4 = (torch.full((B,), 7.0, device=H.DEV),
+                             torch.zeros(1, device=H.DEV),
+                             torch.zeros(B, device=H.DEV),
+                             torch.zeros(2, device=H.DEV))
+  a4 = torch.zeros(B, L * cp, dtype=BF16, device=H.DEV)
+  _lib.call('cg_gp_loss_scale', H.p(slots), P, H.p(norm4), H.p(gp4), H.p(coef4),
+            H.p(d_out), H.p(out4), B, 10.0, 1.0, H.p(gd), H.p(a4), L * cp,
+            H.stream())
+  H.sync()
+  for x, y in ((norm4, nsq3), (gp4, gp3), (coef4, coef3), (out4, out3)):
+    assert torch.equal(x, y), (x, y)
+  assert torch.equal(a4.view(torch.int16), a3.view(torch.int16))
+  # without rows to scale (validate()): the reductions alone
+  norm5 = torch.zeros(B, device=H.DEV)
+  gp5 = torch.zeros(1, device=H.DEV)
+  _lib.call('cg_gp_loss_scale', H.p(slots), P, H.p(norm5), H.p(gp5), H.p(coef4),
+            H.p(d_out), H.p(out4), B, 10.0, 1.0, None, None, 0, H.stream())
+  H.sync()
+  assert torch.equal(norm5, nsq3) and torch.equal(gp5, gp3)
 
 
 def test_adam_colsum_sigmoid_lrelu_metrics():
