@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'calciumgan_amd', 'csrc')
-OUT = os.path.join(ROOT, 'tools', 'probe', '_abl')
+OUT = os.environ.get('ABL_OUT') or os.path.join(ROOT, 'tools', 'probe', '_abl')
 
 
 def rep(s, a, b, count=1):
