@@ -998,6 +998,12 @@ constexpr int kMaxBatch = 6;
 struct WgradMulti {
   int n;
   int gx[kMaxBatch], gy[kMaxBatch], gz[kMaxBatch], tt[kMaxBatch];
+  // entry e is worked on by the workgroups [lo, lo + cnt) only, which share its
+  // K' splits [zofs, zofs + zcnt) of gz (the plain form: every workgroup, every
+  // split).  "Halves": the layers are dealt to two halves of the grid and one
+  // layer's splits are shared between them (two entries), so a workgroup flushes
+  // its accumulators three times per pass instead of once per layer.
+  int lo[kMaxBatch], cnt[kMaxBatch], zofs[kMaxBatch], zcnt[kMaxBatch];
   WgradArgs a[kMaxBatch];
 };
 
@@ -1032,13 +1038,15 @@ __global__ __launch_bounds__(512) void wgrad_multi_kernel(WgradMulti m) {
     // each layer hands its blocks out from another starting id (a multiple of
     // 8: XCD residues stay), so that the idle turns are not always the same
     // workgroups' (the last 32 ran 20 % less: tools/wgrad_trace.py).
-#ifdef CG_WGRAD_NO_SHIFT
-    const int id = (int)blockIdx.x;
-#else
-    int id = (int)blockIdx.x + (li * CG_WGRAD_SHIFT) % (int)gridDim.x;
-    if (id >= (int)gridDim.x) id -= (int)gridDim.x;
+    const int cnt = m.cnt[li];
+    int id = (int)blockIdx.x - m.lo[li];
+    const bool mine = id >= 0 && id < cnt;
+#ifndef CG_WGRAD_NO_SHIFT
+    id += (li * CG_WGRAD_SHIFT) % cnt;
+    if (id >= cnt) id -= cnt;
 #endif
-    if (wgrad_block(m.a[li], gz, id, bx, by, bz)) {
+    if (mine && wgrad_block(m.a[li], m.zcnt[li], id, bx, by, bz)) {
+      bz += m.zofs[li];
       if (m.tt[li] == 128)
         wgrad_body<R, TPW, false, true, 128, ALLT>(m.a[li], bx, by, bz, gz CG_WTR_ARGS);
       else
@@ -1312,6 +1320,91 @@ extern "C" long long cg_wgrad_partials_elems(const cg_wgrad_desc* d) {
   return rc ? -1 : p.part_elems;
 }
 
+// "Halves" form of the batched launch (WgradMulti): deal the layers to two halves
+// of a 256-workgroup grid so that both halves carry the same multiply-adds, the
+// K' splits of one layer shared between them.  Every layer is re-planned with
+// the split count that fills ONE half, so a pass writes (and the reducing launch
+// reads) ~0.6 x the partial sums.  Returns false -- plans untouched -- when the
+// launch does not have this shape or no deal balances within 4 %
+// (CALCIUMGAN_WGRAD_HALVES=0: never).
+static bool plan_halves(const cg_wgrad_desc* descs, int n, WgradPlan* plans,
+                        WgradMulti& m, int& blocks, size_t& lds) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("CALCIUMGAN_WGRAD_HALVES");
+    enabled = !(e && e[0] == '0');
+  }
+  constexpr int G = 128;  // workgroups per half
+  if (!enabled || n < 3 || n + 1 > kMaxBatch) return false;
+  double cost[kMaxBatch];
+  for (int i = 0; i < n; ++i) {
+    const WgradPlan& p = plans[i];
+    if (!p.a.part && !descs[i].store) {
+      // (atomics forms work too, but nothing is gained: no partial sums)
+      return false;
+    }
+    if ((int)wgrad_grid(p.a, p.nsplit) > 2 * G || p.gx * p.gy > G) return false;
+    cost[i] = (double)p.a.M * p.a.taps * (p.gx * 32.0) * (p.gy * 64.0);
+  }
+  int best_s = -1, best_mask = 0;
+  double best = 1e30;
+  for (int sh = 0; sh < n; ++sh)
+    for (int mask = 0; mask < (1 << n); ++mask) {
+      if (mask & (1 << sh)) continue;
+      double c0 = 0, c1 = 0;
+      for (int i = 0; i < n; ++i)
+        if (i != sh) ((mask >> i) & 1 ? c1 : c0) += cost[i];
+      if (c0 == 0 || c1 == 0) continue;
+      const double imb = (c0 > c1 ? c0 - c1 : c1 - c0) / (c0 + c1);
+      if (imb < best) { best = imb; best_s = sh; best_mask = mask; }
+    }
+  if (best_s < 0 || best > 0.04) return false;
+  WgradPlan np[kMaxBatch];
+  int zs = 0;
+  for (int i = 0; i < n; ++i) {
+    cg_wgrad_desc d = descs[i];
+    int z = G / (plans[i].gx * plans[i].gy);
+    for (;; --z) {
+      if (z < 1) return false;
+      d.nsplit = i == best_s ? 2 * z : z;
+      if (plan_wgrad(&d, np[i])) return false;
+      if (np[i].nsplit != d.nsplit) return false;  // (clamped: too few K' tiles)
+      if ((int)wgrad_grid(np[i].a, z) <= G) break;
+    }
+    if (i == best_s) zs = z;
+  }
+  // entries: the two halves' layers alternate (the rotation of the kernel's item
+  // order starts neighbouring 64-id classes on different entries), the shared
+  // layer last
+  int order[kMaxBatch], half[kMaxBatch], ne = 0;
+  {
+    int a0[kMaxBatch], n0 = 0, a1[kMaxBatch], n1 = 0;
+    for (int i = 0; i < n; ++i)
+      if (i != best_s) (((best_mask >> i) & 1) ? a1[n1++] : a0[n0++]) = i;
+    for (int k = 0; k < n0 || k < n1; ++k) {
+      if (k < n0) { order[ne] = a0[k]; half[ne++] = 0; }
+      if (k < n1) { order[ne] = a1[k]; half[ne++] = 1; }
+    }
+    order[ne] = best_s; half[ne++] = 0;
+    order[ne] = best_s; half[ne++] = 1;
+  }
+  m.n = ne;
+  blocks = 2 * G;
+  lds = 0;
+  for (int e = 0; e < ne; ++e) {
+    const int i = order[e];
+    const WgradPlan& p = np[i];
+    m.a[e] = p.a;
+    m.gx[e] = p.gx; m.gy[e] = p.gy; m.gz[e] = p.nsplit; m.tt[e] = p.TT;
+    m.lo[e] = half[e] * G; m.cnt[e] = G;
+    m.zofs[e] = (i == best_s && half[e]) ? zs : 0;
+    m.zcnt[e] = i == best_s ? zs : p.nsplit;
+    if (2 * p.lds > lds) lds = 2 * p.lds;
+  }
+  for (int i = 0; i < n; ++i) plans[i] = np[i];
+  return true;
+}
+
 extern "C" int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream) {
   if (!descs || n < 1) return CG_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -1335,16 +1428,21 @@ extern "C" int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream)
     return 0;
   }
   WgradMulti m;
-  m.n = n;
   int blocks = 0;
   size_t lds = 0;
-  for (int i = 0; i < n; ++i) {
-    const WgradPlan& p = plans[i];
-    m.a[i] = p.a;
-    m.gx[i] = p.gx; m.gy[i] = p.gy; m.gz[i] = p.nsplit; m.tt[i] = p.TT;
-    const int nb = (int)wgrad_grid(p.a, p.nsplit);
-    if (nb > blocks) blocks = nb;
-    if (2 * p.lds > lds) lds = 2 * p.lds;
+  if (!plan_halves(descs, n, plans, m, blocks, lds)) {
+    m.n = n;
+    for (int i = 0; i < n; ++i) {
+      const WgradPlan& p = plans[i];
+      m.a[i] = p.a;
+      m.gx[i] = p.gx; m.gy[i] = p.gy; m.gz[i] = p.nsplit; m.tt[i] = p.TT;
+      const int nb = (int)wgrad_grid(p.a, p.nsplit);
+      if (nb > blocks) blocks = nb;
+      if (2 * p.lds > lds) lds = 2 * p.lds;
+    }
+    for (int i = 0; i < n; ++i) {
+      m.lo[i] = 0; m.cnt[i] = blocks; m.zofs[i] = 0; m.zcnt[i] = m.gz[i];
+    }
   }
   int rc;
   switch (plans[0].tpw) {

@@ -60,6 +60,7 @@ def test_atomics_form_is_still_available_and_close():
     'CALCIUMGAN_FUSE_LN=0', 'CALCIUMGAN_FUSE_UNSHUFFLE=0',
     'CALCIUMGAN_NARROW_LAST=0', 'CALCIUMGAN_FOLD_SCALE=0',
     'CALCIUMGAN_SWP_TILES=0', 'CALCIUMGAN_WGRAD_XCD=0', 'CALCIUMGAN_SPLIT_K=0',
+    'CALCIUMGAN_WGRAD_HALVES=0',
     'CALCIUMGAN_SPLIT_SEGMENTS=1', 'CALCIUMGAN_SWP_LEAN_EPI=1'])
 def test_every_documented_switch_is_a_working_configuration(knob):
   """README's switches select older / alternative forms of the same arithmetic.
