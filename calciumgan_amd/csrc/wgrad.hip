@@ -1332,7 +1332,7 @@ static bool plan_halves(const cg_wgrad_desc* descs, int n, WgradPlan* plans,
   static int enabled = -1;
   if (enabled < 0) {
     const char* e = getenv("CALCIUMGAN_WGRAD_HALVES");
-    enabled = !(e && e[0] == '0');
+    enabled = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;  // 2: print deals
   }
   constexpr int G = 128;  // workgroups per half
   if (!enabled || n < 3 || n + 1 > kMaxBatch) return false;
@@ -1346,33 +1346,54 @@ static bool plan_halves(const cg_wgrad_desc* descs, int n, WgradPlan* plans,
     if ((int)wgrad_grid(p.a, p.nsplit) > 2 * G || p.gx * p.gy > G) return false;
     cost[i] = (double)p.a.M * p.a.taps * (p.gx * 32.0) * (p.gy * 64.0);
   }
+  // split counts that fill ONE half: z_ex as a half's own layer, 2 * z_sh as the
+  // layer both halves share (whole XCD groups of the block order must fit)
+  WgradPlan pex[kMaxBatch], psh[kMaxBatch];
+  int z_ex[kMaxBatch], z_sh[kMaxBatch];
+  double t_plain = 0;
+  for (int i = 0; i < n; ++i) {
+    const int tiles = plans[i].gx * plans[i].gy;
+    t_plain += cost[i] / ((double)tiles * plans[i].nsplit);
+    z_ex[i] = z_sh[i] = 0;
+    for (int shared = 0; shared < 2; ++shared) {
+      cg_wgrad_desc d = descs[i];
+      WgradPlan& q = shared ? psh[i] : pex[i];
+      for (int z = G / tiles; z >= 1; --z) {
+        d.nsplit = shared ? 2 * z : z;
+        if (plan_wgrad(&d, q)) return false;
+        if (q.nsplit != d.nsplit) continue;  // (clamped: too few K' tiles)
+        if ((int)wgrad_grid(q.a, z) <= G) { (shared ? z_sh : z_ex)[i] = z; break; }
+      }
+    }
+  }
+  // the deal with the shortest longest half, in per-workgroup time (one item of
+  // every layer the half holds): cost / items, items = tiles x splits
   int best_s = -1, best_mask = 0;
   double best = 1e30;
-  for (int sh = 0; sh < n; ++sh)
+  for (int sh = 0; sh < n; ++sh) {
+    if (!z_sh[sh]) continue;
+    const double tsh = cost[sh] / ((double)plans[sh].gx * plans[sh].gy * 2 * z_sh[sh]);
     for (int mask = 0; mask < (1 << n); ++mask) {
       if (mask & (1 << sh)) continue;
-      double c0 = 0, c1 = 0;
-      for (int i = 0; i < n; ++i)
-        if (i != sh) ((mask >> i) & 1 ? c1 : c0) += cost[i];
-      if (c0 == 0 || c1 == 0) continue;
-      const double imb = (c0 > c1 ? c0 - c1 : c1 - c0) / (c0 + c1);
-      if (imb < best) { best = imb; best_s = sh; best_mask = mask; }
+      double t0 = tsh, t1 = tsh;
+      bool ok = true;
+      int n0 = 0, n1 = 0;
+      for (int i = 0; i < n && ok; ++i) {
+        if (i == sh) continue;
+        if (!z_ex[i]) { ok = false; break; }
+        const double ti = cost[i] / ((double)plans[i].gx * plans[i].gy * z_ex[i]);
+        if ((mask >> i) & 1) { t1 += ti; ++n1; } else { t0 += ti; ++n0; }
+      }
+      if (!ok || !n0 || !n1) continue;
+      const double tm = t0 > t1 ? t0 : t1;
+      if (tm < best) { best = tm; best_s = sh; best_mask = mask; }
     }
-  if (best_s < 0 || best > 0.04) return false;
-  WgradPlan np[kMaxBatch];
-  int zs = 0;
-  for (int i = 0; i < n; ++i) {
-    cg_wgrad_desc d = descs[i];
-    int z = G / (plans[i].gx * plans[i].gy);
-    for (;; --z) {
-      if (z < 1) return false;
-      d.nsplit = i == best_s ? 2 * z : z;
-      if (plan_wgrad(&d, np[i])) return false;
-      if (np[i].nsplit != d.nsplit) return false;  // (clamped: too few K' tiles)
-      if ((int)wgrad_grid(np[i].a, z) <= G) break;
-    }
-    if (i == best_s) zs = z;
   }
+  // (the plain form's own figure has its idle workgroups in it: allow 4 % on top)
+  if (best_s < 0 || best > 1.04 * t_plain) return false;
+  WgradPlan np[kMaxBatch];
+  for (int i = 0; i < n; ++i) np[i] = i == best_s ? psh[i] : pex[i];
+  const int zs = z_sh[best_s];
   // entries: the two halves' layers alternate (the rotation of the kernel's item
   // order starts neighbouring 64-id classes on different entries), the shared
   // layer last
@@ -1402,6 +1423,13 @@ static bool plan_halves(const cg_wgrad_desc* descs, int n, WgradPlan* plans,
     if (2 * p.lds > lds) lds = 2 * p.lds;
   }
   for (int i = 0; i < n; ++i) plans[i] = np[i];
+  if (enabled == 2) {
+    fprintf(stderr, "cg_wgrad_batched halves: shared layer %d (2 x %d splits), half 1 = mask 0x%x, "
+            "longest half %.3f of the plain form's time; splits", best_s, zs, best_mask,
+            best / t_plain);
+    for (int i = 0; i < n; ++i) fprintf(stderr, " %d", np[i].nsplit);
+    fprintf(stderr, "\n");
+  }
   return true;
 }
 
