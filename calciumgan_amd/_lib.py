@@ -108,6 +108,9 @@ SIGNATURES = {
     'cg_struct_size': [c_i],
     'cg_tile_shape': [c_i, C.POINTER(c_i), C.POINTER(c_i)],
     'cg_debug_lean_epilogue': [c_i],
+    'cg_debug_wgrad_flex': [c_i],
+    'cg_wgrad_flex_plan': [C.POINTER(WgradDesc), c_i, c_i, C.POINTER(c_i), c_ll,
+                           C.POINTER(c_i)],
     'cg_profile_enable': [c_i],
     'cg_profile_collect': [C.POINTER(c_f), C.POINTER(c_i), c_i],
     'cg_swconv': [C.POINTER(ConvDesc), c_vp],
@@ -174,7 +177,7 @@ SIGNATURES = {
 _RESTYPES = {'cg_packed_elems': c_ll, 'cg_pack_plan_bytes': c_ll,
              'cg_pack_plan_build': c_ll, 'cg_wgrad_partials_elems': c_ll,
              'cg_dense_wgrad_ws_elems': c_ll, 'cg_rowsumsq_ws_elems': c_ll,
-             'cg_reduce_ws_elems': c_ll}
+             'cg_reduce_ws_elems': c_ll, 'cg_wgrad_flex_plan': c_ll}
 
 _libs = {}       # precision -> ctypes handle
 _active = 'bf16'  # precision of the library `call` / `load()` address

@@ -18,6 +18,12 @@
 // distinct 32-B bank groups (conflict-free).
 #include "cg_common.h"
 
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
 namespace {
 
 // -DCG_WGRAD_TRACE (tools/wgrad_trace.sh; never in the product library): cycles a
@@ -306,7 +312,7 @@ __device__ __forceinline__ void lds_wait_set(RingFrags& f, int set) {
 template <int TT>
 __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
                                                 unsigned char* smem, int bx,
-                                                int by, int bz, int gz,
+                                                int by, int bz, int gz, int tn,
                                                 bool do_bias,
                                                 f32x4 (&acc)[3][2][4],
                                                 float& bs0, float& bs1
@@ -315,7 +321,9 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
   using std::integral_constant;
   constexpr int KSTEPS = TT / 32;
   static_assert(KSTEPS % 2 == 0, "a tile starts on fragment set 0");
-  const int n_i = bz < a.ntiles ? (a.ntiles - bz + gz - 1) / gz : 0;
+  // tiles bz, bz + gz, ... : `tn` of them (the flex form's contiguous range, gz =
+  // 1), or every one below ntiles
+  const int n_i = tn >= 0 ? tn : (bz < a.ntiles ? (a.ntiles - bz + gz - 1) / gz : 0);
   if (n_i == 0) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -618,10 +626,13 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
 // sample: wgrad_compute runs its software-pipelined order.
 // (bx, by, bz) / gz: this workgroup's (cx chunk, cg chunk, K' split) and the
 // number of K' splits -- blockIdx / gridDim.z for a single launch, decoded from
-// the linear block id by the multi-layer kernel below.
+// the linear block id by the multi-layer kernel below.  tn / pslot >= 0 (the flex
+// form, ring-staged only): the item is the `tn` CONSECUTIVE tiles from bz on (gz =
+// 1) and leaves its partial sums (and bias column sums) in slot `pslot`.
 template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, int ALLT>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
-                                           int bz, int gz CG_WTR_PARAMS) {
+                                           int bz, int gz, int tn,
+                                           int pslot CG_WTR_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(!ROWSPLIT || TT == 256, "row-split tiles are 256 rows");
   constexpr int NG = TT * 8 / 512;  // g pieces per thread (1, 2 or 4)
@@ -655,7 +666,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
 
   if constexpr (ALLT == 2) {
     static_assert(R == 2 && TPW == 3 && PIPE && !ROWSPLIT, "ring-staged form");
-    wgrad_ring_loop<TT>(a, smem, bx, by, bz, gz, do_bias, acc, bs0, bs1 CG_WTR_ARGS);
+    wgrad_ring_loop<TT>(a, smem, bx, by, bz, gz, tn, do_bias, acc, bs0, bs1 CG_WTR_ARGS);
     CG_WTR(wtr, wtt, 1);  // K' loop
   } else if (PIPE) {
     // per-thread piece coordinates (fixed across tiles)
@@ -808,7 +819,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
 #pragma unroll
       for (int k = 1; k < 16; ++k) t += red[k * 64 + tid];
       if (a.bias_part)
-        a.bias_part[((long long)bz * a.pgy + by) * 64 + tid] = t;
+        a.bias_part[(pslot >= 0 ? (long long)pslot : (long long)bz * a.pgy + by) * 64 +
+                    tid] = t;
       else if (cg0 + tid < a.Cg_real) {
         if (a.direct_store) a.dbias[cg0 + tid] = t;
         else atomicAdd(a.dbias + cg0 + tid, t);
@@ -819,8 +831,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
   if (!ROWSPLIT && a.part) {
     // accumulators in register order: every store instruction of a wave is one
     // contiguous 1 KiB run; block (bz, by, bx), slot (s, mt, nt), thread
-    float* pb = a.part + ((long long)(bz * a.pgy + by) * a.pgx + bx) *
-                             (TPW * 8 * 2048) + tid * 4;
+    const long long ps =
+        pslot >= 0 ? (long long)pslot : (long long)(bz * a.pgy + by) * a.pgx + bx;
+    float* pb = a.part + ps * (TPW * 8 * 2048) + tid * 4;
 #pragma unroll
     for (int s = 0; s < TPW; ++s)
 #pragma unroll
@@ -893,7 +906,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a, int gz) {
   unsigned wtr[kWTraceParts] = {};
   unsigned wtt = 0;
 #endif
-  wgrad_body<R, TPW, ROWSPLIT, PIPE, TT, ALLT>(a, bx, by, bz, gz CG_WTR_ARGS);
+  wgrad_body<R, TPW, ROWSPLIT, PIPE, TT, ALLT>(a, bx, by, bz, gz, -1, -1 CG_WTR_ARGS);
 }
 
 // Second stage of the partial-sum path: an element (block tile, slot, tid) is one
@@ -1048,9 +1061,9 @@ __global__ __launch_bounds__(512) void wgrad_multi_kernel(WgradMulti m) {
     if (mine && wgrad_block(m.a[li], m.zcnt[li], id, bx, by, bz)) {
       bz += m.zofs[li];
       if (m.tt[li] == 128)
-        wgrad_body<R, TPW, false, true, 128, ALLT>(m.a[li], bx, by, bz, gz CG_WTR_ARGS);
+        wgrad_body<R, TPW, false, true, 128, ALLT>(m.a[li], bx, by, bz, gz, -1, -1 CG_WTR_ARGS);
       else
-        wgrad_body<R, TPW, false, true, 64, ALLT>(m.a[li], bx, by, bz, gz CG_WTR_ARGS);
+        wgrad_body<R, TPW, false, true, 64, ALLT>(m.a[li], bx, by, bz, gz, -1, -1 CG_WTR_ARGS);
     }
     CG_WTR(wtr, wtt, 3);  // (items this workgroup has no share of; flush of atomics forms)
     __syncthreads();  // LDS is reused by the next item
@@ -1061,6 +1074,156 @@ __global__ __launch_bounds__(512) void wgrad_multi_kernel(WgradMulti m) {
     for (int k = 0; k < kWTraceParts; ++k)
       g_wgrad_trace[((int)blockIdx.x * 8 + (int)(threadIdx.x >> 6)) * kWTraceParts + k] = wtr[k];
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// "Flex" form of the batched launch (round 5): the layers run SIDE BY SIDE.  All
+// (layer, output tile, K' tile) work of the pass is one sequence, ordered (layer,
+// column, K'), and cut into equal-cost shares; a share is a contiguous K' range
+// that may end inside one column and continue in the next.  A column is up to S
+// output tiles that stream the same x and / or g tiles (4 x 1, 1 x 4 or 2 x 2 of
+// the (cx, cg) block grid); a TEAM of S workgroups, consecutive slots of one XCD,
+// walks a share in step -- member m on the column's tile m -- so an operand tile
+// is fetched into that XCD's L2 once, as in the XCD-grouped order above.  A
+// workgroup flushes its accumulators once per (share, column) it touches: ~1.4
+// times per pass instead of once per layer (plain form) or three times (halves),
+// and the pass is balanced to one K' tile instead of to whole split counts.
+// The host plans the shares (plan_flex) and hands every workgroup its items
+// through a table in device memory; partial sums of one output tile occupy
+// consecutive slots, in ascending K' order, and wgrad_flex_reduce_kernel adds
+// them in that order (one owner per dW element: deterministic).
+// ---------------------------------------------------------------------------
+constexpr int kFlexMaxItems = 8;  // per workgroup
+constexpr int kFlexItemInts = 6;  // layer (< 0: end), bx, by, first K' tile, tiles, slot
+
+struct WgradFlex {
+  int n;
+  int tt[kMaxBatch];
+  const int* table;  // [workgroups][kFlexMaxItems][kFlexItemInts]
+  WgradArgs a[kMaxBatch];
+};
+
+template <int R, int TPW, int ALLT>
+__global__ __launch_bounds__(512) void wgrad_flex_kernel(WgradFlex m) {
+#ifdef CG_WGRAD_TRACE
+  unsigned wtr[kWTraceParts] = {};
+  unsigned wtt;
+  {
+    unsigned long long n_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n_)::"memory");
+    wtt = (unsigned)n_;
+  }
+#endif
+  const int* it = m.table + (size_t)blockIdx.x * (kFlexMaxItems * kFlexItemInts);
+  for (int k = 0; k < kFlexMaxItems; ++k, it += kFlexItemInts) {
+    const int li = __builtin_amdgcn_readfirstlane(it[0]);
+    if (li < 0) break;
+    const int bx = __builtin_amdgcn_readfirstlane(it[1]);
+    const int by = __builtin_amdgcn_readfirstlane(it[2]);
+    const int k0 = __builtin_amdgcn_readfirstlane(it[3]);
+    const int kn = __builtin_amdgcn_readfirstlane(it[4]);
+    const int ps = __builtin_amdgcn_readfirstlane(it[5]);
+    if (m.tt[li] == 128)
+      wgrad_body<R, TPW, false, true, 128, ALLT>(m.a[li], bx, by, k0, 1, kn, ps CG_WTR_ARGS);
+    else
+      wgrad_body<R, TPW, false, true, 64, ALLT>(m.a[li], bx, by, k0, 1, kn, ps CG_WTR_ARGS);
+    CG_WTR(wtr, wtt, 3);
+    __syncthreads();  // LDS is reused by the next item
+    CG_WTR(wtr, wtt, 4);
+  }
+#ifdef CG_WGRAD_TRACE
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 256)
+    for (int k = 0; k < kWTraceParts; ++k)
+      g_wgrad_trace[((int)blockIdx.x * 8 + (int)(threadIdx.x >> 6)) * kWTraceParts + k] = wtr[k];
+#endif
+}
+
+// Reducing launch of the flex form: output tile t of a layer owns the slots
+// [tiles[2 t], tiles[2 t] + tiles[2 t + 1]); otherwise as wgrad_reduce_kernel.
+struct FlexReduceItem {
+  const float* part;
+  float* dw;
+  const int* tiles;        // [gx * gy][2] in device memory
+  int gx, gy, tpw, taps, Cx_real, Cg_real;
+  int store, zc;
+  const float* bias_part;  // [slot][64] or null
+  float* dbias;
+};
+struct FlexReduceArgs {
+  int n;
+  FlexReduceItem it[kMaxBatch];
+};
+
+__global__ __launch_bounds__(256) void wgrad_flex_reduce_kernel(FlexReduceArgs ra) {
+  const FlexReduceItem& it = ra.it[blockIdx.y];
+  __shared__ f32x4 red[256];
+  if (it.bias_part && blockIdx.x == 0) {
+    // conv bias gradient: column sums of the (cx block 0, cg block) tiles' items,
+    // in slot (= ascending K') order
+    for (int c = threadIdx.x; c < it.gy * 64; c += 256) {
+      const int t = (c >> 6) * it.gx;
+      const int p0 = it.tiles[2 * t], cnt = it.tiles[2 * t + 1];
+      float s = 0.f;
+      for (int z = 0; z < cnt; ++z) s += it.bias_part[(long long)(p0 + z) * 64 + (c & 63)];
+      if (c < it.Cg_real) {
+        if (it.store) it.dbias[c] = s;
+        else it.dbias[c] += s;
+      }
+    }
+  }
+  const int per_tile = it.tpw * 8 * 512;  // float4 per slot
+  const long long total = (long long)it.gx * it.gy * per_tile;
+  const int zc = it.zc;
+  const int epb = 256 / zc;  // elements per block and round (divides per_tile: one tile)
+  const int el = (int)threadIdx.x % epb;
+  const int zi = (int)threadIdx.x / epb;
+  for (long long base = (long long)blockIdx.x * epb; base < total;
+       base += (long long)gridDim.x * epb) {
+    const long long e = base + el;
+    const int tile = (int)(base / per_tile);
+    const int rem = (int)(e - (long long)tile * per_tile);
+    const int p0 = it.tiles[2 * tile], cnt = it.tiles[2 * tile + 1];
+    const int chunk = (cnt + zc - 1) / zc;
+    const int z0 = zi * chunk;
+    const int z1 = z0 + chunk < cnt ? z0 + chunk : cnt;
+    const float* p = it.part + ((long long)p0 * per_tile + rem) * 4;
+    const long long stride = (long long)per_tile * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int z = z0; z < z1; z += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (z + k < z1) v[k] = *reinterpret_cast<const f32x4*>(p + (z + k) * stride);
+      }
+      sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    if (zc > 1) {
+      red[threadIdx.x] = sum;
+      __syncthreads();
+      if (zi == 0)
+        for (int k = 1; k < zc; ++k) sum += red[k * epb + el];
+      __syncthreads();
+    }
+    if (zi != 0) continue;
+    const int slot = rem >> 9;
+    const int tid = rem & 511;
+    const int bx = tile % it.gx, by = tile / it.gx;
+    const int s = slot >> 3, mt = (slot >> 2) & 1, nt = slot & 3;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int tap = wave + 8 * s;
+    const int cg = by * 64 + nt * 16 + (lane & 15);
+    if (tap < it.taps && cg < it.Cg_real) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cx = bx * 32 + mt * 16 + 4 * (lane >> 4) + r;
+        if (cx < it.Cx_real) {
+          float* q = it.dw + ((long long)tap * it.Cx_real + cx) * it.Cg_real + cg;
+          *q = it.store ? sum[r] : *q + sum[r];
+        }
+      }
+    }
+  }
 }
 
 inline int ilog2(int v) {
@@ -1433,6 +1596,341 @@ static bool plan_halves(const cg_wgrad_desc* descs, int n, WgradPlan* plans,
   return true;
 }
 
+// ---------------------------------------------------------------------------
+// Host side of the flex form: the share plan of one set of layer geometries,
+// built once and cached with its device table.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct FlexPlan {
+  bool ok = false;
+  int S = 4;       // team size
+  int nteams = 0;
+  int nwg = 0;     // grid
+  std::vector<int> host;  // items [nwg][kFlexMaxItems][kFlexItemInts], then per-layer tile tables
+  int* dev = nullptr;
+  int nslots[kMaxBatch] = {};
+  int tile_ofs[kMaxBatch] = {};  // ints from the start of the table
+  int zc[kMaxBatch] = {};
+  int nitems = 0;                // (team, column) pairs x live members
+};
+
+// 0: never, 1: when every team gets a worthwhile share (default), 2: whenever the
+// launch has the ring form (tests: small shapes)
+std::atomic<int> g_flex_mode{-1};
+int flex_mode() {
+  int m = g_flex_mode.load();
+  if (m < 0) {
+    const char* e = getenv("CALCIUMGAN_WGRAD_FLEX");
+    m = e ? atoi(e) : 1;
+    if (m < 0 || m > 2) m = 1;
+    g_flex_mode.store(m);
+  }
+  return m;
+}
+int flex_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+struct FlexCol {
+  int layer, cw, ch, bx0, by0;
+  long long n;     // K' tiles
+  long long cost;  // per K' tile, in team time
+};
+
+// plans[i]: the standard plan of layer i (geometry only is read)
+void plan_flex(const WgradPlan* plans, int n, int mode, FlexPlan& fp) {
+  fp.ok = false;
+  // cost of a K' tile in team time: 64-row tiles pay the per-tile barrier and the
+  // DMA issue twice per 128 rows
+  const int c128 = 16, c64 = flex_env("CALCIUMGAN_WGRAD_FLEX_C64", 9);
+  const int snap = flex_env("CALCIUMGAN_WGRAD_FLEX_SNAP", 4);
+  const long long min_share = 8 * c128;  // a team's share must be worth its set-up
+  // team size: the largest whose padded columns cost at most 5 % over the best
+  int bestS = 0;
+  double ts[5] = {0, 0, 0, 0, 0};
+  std::vector<FlexCol> cols_of[5];
+  const int force_s = flex_env("CALCIUMGAN_WGRAD_FLEX_TEAM", 0);
+  for (int S = 4; S >= 1; S >>= 1) {
+    if (force_s && S != force_s) continue;
+    std::vector<FlexCol>& cols = cols_of[S];
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+      const WgradPlan& p = plans[i];
+      // column shape: fewest columns (least padding), then least re-read bytes
+      const double xb = (double)p.a.nB * p.a.Lx * p.a.Cx, gb = (double)p.a.M * p.a.Cg;
+      int bcw = 1, bch = 1;
+      long long bcols = -1;
+      double bbytes = 0;
+      for (int cw = 1; cw <= S; cw <<= 1) {
+        const int ch = S / cw;
+        const int ncx = (p.gx + cw - 1) / cw, ncy = (p.gy + ch - 1) / ch;
+        const long long nc = (long long)ncx * ncy;
+        const double bytes = ncy * xb + ncx * gb;
+        if (bcols < 0 || nc < bcols || (nc == bcols && bytes < bbytes)) {
+          bcols = nc; bbytes = bytes; bcw = cw; bch = ch;
+        }
+      }
+      const long long cost = p.TT == 128 ? c128 : c64;
+      for (int by0 = 0; by0 < p.gy; by0 += bch)
+        for (int bx0 = 0; bx0 < p.gx; bx0 += bcw) {
+          cols.push_back(FlexCol{i, bcw, bch, bx0, by0, (long long)p.a.ntiles, cost});
+          total += (long long)p.a.ntiles * cost;
+        }
+    }
+    ts[S] = (double)total * S;  // / 256 workgroups
+  }
+  {
+    double tmin = 1e300;
+    for (int S = 1; S <= 4; S <<= 1)
+      if (ts[S] > 0 && ts[S] < tmin) tmin = ts[S];
+    for (int S = 4; S >= 1; S >>= 1)
+      if (ts[S] > 0 && ts[S] <= 1.05 * tmin) { bestS = S; break; }
+  }
+  if (!bestS) return;
+  const int S = bestS;
+  const std::vector<FlexCol>& cols = cols_of[S];
+  long long total = 0;
+  for (const FlexCol& c : cols) total += c.n * c.cost;
+  const int max_teams = 256 / S;
+  int nteams = max_teams;
+  if (total < (long long)nteams * min_share) {
+    if (mode < 2) return;  // too little work: the split forms are the better fit
+    nteams = (int)(total / min_share);
+    if (nteams < 1) nteams = 1;
+  }
+  // cut t = (column, K' tile); tiny heads / tails of a column are snapped away
+  struct Cut { int col; long long k; };
+  std::vector<Cut> cuts(nteams + 1);
+  {
+    size_t ci = 0;
+    long long start = 0;  // cost at the start of column ci
+    for (int t = 0; t <= nteams; ++t) {
+      const long long b = t == nteams ? total : (long long)((__int128)total * t / nteams);
+      while (ci < cols.size() && start + cols[ci].n * cols[ci].cost <= b) {
+        start += cols[ci].n * cols[ci].cost;
+        ++ci;
+      }
+      if (ci >= cols.size()) { cuts[t] = Cut{(int)cols.size(), 0}; continue; }
+      long long k = (b - start) / cols[ci].cost;
+      // (snapping moves a cut by at most ~2 % of a share)
+      long long sn = total / nteams / (50 * cols[ci].cost);
+      sn = sn < 1 ? 1 : (sn > snap ? snap : sn);
+      if (k < sn) k = 0;
+      if (cols[ci].n - k < sn) { cuts[t] = Cut{(int)ci + 1, 0}; continue; }
+      cuts[t] = Cut{(int)ci, k};
+    }
+    cuts[0] = Cut{0, 0};
+    cuts[nteams] = Cut{(int)cols.size(), 0};
+  }
+  const int nwg = (nteams + 7) / 8 * 8 * S;
+  fp.S = S; fp.nteams = nteams; fp.nwg = nwg;
+  const size_t items_ints = (size_t)nwg * kFlexMaxItems * kFlexItemInts;
+  size_t tiles_ints = 0;
+  for (int i = 0; i < n; ++i) {
+    fp.tile_ofs[i] = (int)(items_ints + tiles_ints);
+    tiles_ints += (size_t)plans[i].gx * plans[i].gy * 2;
+  }
+  fp.host.assign(items_ints + tiles_ints, 0);
+  for (int w = 0; w < nwg; ++w)
+    for (int k = 0; k < kFlexMaxItems; ++k)
+      fp.host[((size_t)w * kFlexMaxItems + k) * kFlexItemInts] = -1;
+  // pass 1: count the items of every output tile; pass 2: slots + table rows
+  std::vector<int> wg_items(nwg, 0);
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) {
+      for (int i = 0; i < n; ++i) {
+        int* tl = fp.host.data() + fp.tile_ofs[i];
+        int run = 0, most = 0;
+        for (int t = 0; t < plans[i].gx * plans[i].gy; ++t) {
+          const int cnt = tl[2 * t + 1];
+          tl[2 * t] = run;
+          tl[2 * t + 1] = 0;  // refilled below, in K' order
+          run += cnt;
+          if (cnt > most) most = cnt;
+        }
+        fp.nslots[i] = run;
+        fp.zc[i] = 1;
+        while (fp.zc[i] < 8 && (most + fp.zc[i] - 1) / fp.zc[i] > 8) fp.zc[i] *= 2;
+      }
+    }
+    for (int t = 0; t < nteams; ++t) {
+      const Cut a = cuts[t], b = cuts[t + 1];
+      for (int ci = a.col; ci <= b.col && ci < (int)cols.size(); ++ci) {
+        const FlexCol& c = cols[ci];
+        const long long k0 = ci == a.col ? a.k : 0;
+        const long long k1 = ci == b.col ? b.k : c.n;
+        if (k1 <= k0) continue;
+        const WgradPlan& p = plans[c.layer];
+        int* tl = fp.host.data() + fp.tile_ofs[c.layer];
+        for (int m = 0; m < c.cw * c.ch; ++m) {
+          const int bx = c.bx0 + m % c.cw, by = c.by0 + m / c.cw;
+          if (bx >= p.gx || by >= p.gy) continue;
+          const int tile = by * p.gx + bx;
+          if (pass == 0) { ++tl[2 * tile + 1]; continue; }
+          const int wg = ((t >> 3) * S + m) * 8 + (t & 7);
+          const int k = wg_items[wg]++;
+          if (k >= kFlexMaxItems) return;  // (fp.ok stays false)
+          int* row = fp.host.data() + ((size_t)wg * kFlexMaxItems + k) * kFlexItemInts;
+          row[0] = c.layer; row[1] = bx; row[2] = by;
+          row[3] = (int)k0; row[4] = (int)(k1 - k0);
+          row[5] = tl[2 * tile] + tl[2 * tile + 1]++;
+          ++fp.nitems;
+        }
+      }
+    }
+  }
+  fp.ok = true;
+}
+
+std::mutex g_flex_mutex;
+std::map<std::vector<long long>, FlexPlan*> g_flex_cache;
+
+// the cached plan of this geometry set, its table uploaded on `s` when new
+FlexPlan* flex_plan_for(const WgradPlan* plans, int n, int mode, hipStream_t s) {
+  std::vector<long long> key;
+  key.push_back(cg_device_index());
+  key.push_back(mode);
+  for (int i = 0; i < n; ++i) {
+    const WgradPlan& p = plans[i];
+    for (long long v : {(long long)p.gx, (long long)p.gy, (long long)p.TT, (long long)p.a.ntiles,
+                        (long long)p.a.nB, (long long)p.a.Lx, (long long)p.a.Cx, (long long)p.a.M,
+                        (long long)p.a.Cg})
+      key.push_back(v);
+  }
+  std::lock_guard<std::mutex> lock(g_flex_mutex);
+  auto f = g_flex_cache.find(key);
+  if (f != g_flex_cache.end()) return f->second;
+  FlexPlan* fp = new FlexPlan;  // (lives as long as the process: graphs keep its table)
+  plan_flex(plans, n, mode, *fp);
+  if (fp->ok) {
+    const size_t bytes = fp->host.size() * sizeof(int);
+    // (a first call inside a stream capture: the allocation is not a captured
+    // operation, the copy becomes a node that re-sends the same bytes)
+    hipStreamCaptureMode cm = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&cm);
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&fp->dev), bytes);
+    (void)hipThreadExchangeStreamCaptureMode(&cm);
+    if (e != hipSuccess ||
+        hipMemcpyAsync(fp->dev, fp->host.data(), bytes, hipMemcpyHostToDevice, s) != hipSuccess) {
+      (void)hipGetLastError();
+      fp->ok = false;
+    }
+    if (fp->ok && flex_env("CALCIUMGAN_WGRAD_FLEX_PRINT", 0)) {
+      fprintf(stderr, "cg_wgrad_batched flex: %d layers, teams of %d x %d, %d workgroups, %d items, slots",
+              n, fp->S, fp->nteams, fp->nwg, fp->nitems);
+      for (int i = 0; i < n; ++i) fprintf(stderr, " %d", fp->nslots[i]);
+      fprintf(stderr, "\n");
+    }
+  }
+  g_flex_cache[key] = fp;
+  return fp;
+}
+
+template <int TPW, int ALLT>
+int launch_flex(const WgradFlex& m, int blocks, size_t lds, hipStream_t s) {
+  static CgPerDeviceFlag attr_set;
+  if (!attr_set.test()) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&wgrad_flex_kernel<2, TPW, ALLT>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set.mark();
+  }
+  CG_LAUNCH_PROF(CG_FAMILY_WGRAD, (wgrad_flex_kernel<2, TPW, ALLT>), dim3(blocks),
+                 dim3(512), lds, s, m);
+  CG_LAUNCH_CHECK();
+}
+
+// 0: done; > 0: HIP error; < 0: not this form (the caller takes the split forms)
+int run_flex(const cg_wgrad_desc* descs, int n, WgradPlan* plans, hipStream_t s) {
+  const int mode = flex_mode();
+  if (!mode || n > kMaxBatch) return -1;
+  for (int i = 0; i < n; ++i) {
+    const WgradPlan& p = plans[i];
+    if (!p.a.ring || p.tpw != 3 || !descs[i].partials) return -1;
+  }
+  FlexPlan* fp = flex_plan_for(plans, n, mode, s);
+  if (!fp->ok) return -1;
+  WgradFlex m;
+  FlexReduceArgs ra;
+  m.n = n;
+  m.table = fp->dev;
+  ra.n = n;
+  size_t lds = 0;
+  long long most = 0;
+  for (int i = 0; i < n; ++i) {
+    const WgradPlan& p = plans[i];
+    const long long per_slot = (long long)p.tpw * 8 * 2048;
+    const long long dw_part = (long long)fp->nslots[i] * per_slot;
+    const long long bias = descs[i].dbias ? (long long)fp->nslots[i] * 64 : 0;
+    if (descs[i].partials_elems < dw_part + bias) return -1;
+    m.a[i] = p.a;
+    m.a[i].part = descs[i].partials;
+    m.a[i].bias_part = bias ? descs[i].partials + dw_part : nullptr;
+    m.a[i].direct_store = 0;
+    m.tt[i] = p.TT;
+    if (2 * p.lds > lds) lds = 2 * p.lds;
+    FlexReduceItem& it = ra.it[i];
+    it.part = m.a[i].part; it.dw = p.a.dw;
+    it.tiles = fp->dev + fp->tile_ofs[i];
+    it.gx = p.gx; it.gy = p.gy; it.tpw = p.tpw; it.taps = p.a.taps;
+    it.Cx_real = p.a.Cx_real; it.Cg_real = p.a.Cg_real;
+    it.store = descs[i].store ? 1 : 0;
+    it.zc = fp->zc[i];
+    it.bias_part = m.a[i].bias_part; it.dbias = p.a.dbias;
+    const long long t = (long long)p.gx * p.gy * p.tpw * 8 * 512 * it.zc;
+    if (t > most) most = t;
+  }
+  int rc = launch_flex<3, 2>(m, fp->nwg, lds, s);
+  if (rc) return rc > 0 ? rc : 1;
+  long long bx = (most + 255) / 256;
+  if (bx > 2048) bx = 2048;
+  CG_LAUNCH_PROF(CG_FAMILY_WGRAD, wgrad_flex_reduce_kernel, dim3((unsigned)bx, n), dim3(256),
+                 0, s, ra);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// The share plan of a batched launch, for inspection (host only, no device call):
+// the table wgrad_flex_kernel would read -- items [nwg][8][6] = (layer | -1, bx,
+// by, first K' tile, tiles, slot), then per layer [gx * gy][2] = (first slot,
+// slots) -- is copied to `out` (when it holds the returned count of ints) and
+// info[0..3] = team size, teams, workgroups, items, info[4 + i] = slots of layer
+// i, info[10 + i] = int offset of layer i's tile table.  < 0: this launch does not
+// take the flex form under `mode` (1 | 2).
+extern "C" long long cg_wgrad_flex_plan(const cg_wgrad_desc* descs, int n, int mode,
+                                        int* out, long long out_ints, int* info) {
+  if (!descs || n < 2 || n > kMaxBatch || mode < 1 || mode > 2) return -1;
+  WgradPlan plans[kMaxBatch];
+  for (int i = 0; i < n; ++i) {
+    if (plan_wgrad(descs + i, plans[i])) return -1;
+    const WgradPlan& p = plans[i];
+    if (p.rowsplit || !p.pipe || p.a.nseg != 1 || !p.a.ring || p.tpw != 3) return -1;
+  }
+  FlexPlan fp;
+  plan_flex(plans, n, mode, fp);
+  if (!fp.ok) return -1;
+  if (info) {
+    info[0] = fp.S; info[1] = fp.nteams; info[2] = fp.nwg; info[3] = fp.nitems;
+    for (int i = 0; i < kMaxBatch; ++i) {
+      info[4 + i] = i < n ? fp.nslots[i] : 0;
+      info[10 + i] = i < n ? fp.tile_ofs[i] : 0;
+    }
+  }
+  if (out && out_ints >= (long long)fp.host.size())
+    memcpy(out, fp.host.data(), fp.host.size() * sizeof(int));
+  return (long long)fp.host.size();
+}
+
+extern "C" int cg_debug_wgrad_flex(int mode) {
+  const int was = flex_mode();
+  if (mode >= 0 && mode <= 2) g_flex_mode.store(mode);
+  return was;
+}
+
 extern "C" int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream) {
   if (!descs || n < 1) return CG_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -1454,6 +1952,10 @@ extern "C" int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream)
       if (rc) return rc;
     }
     return 0;
+  }
+  {
+    const int rc = run_flex(descs, n, plans, s);
+    if (rc >= 0) return rc;
   }
   WgradMulti m;
   int blocks = 0;

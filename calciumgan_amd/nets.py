@@ -108,8 +108,8 @@ class FlatParams(object):
 # -- the penalty norm, conv / LayerNorm / Dense bias and scale gradients, the
 # critic head's weight gradient, the signal metrics -- goes through per-block
 # partial rows and a finishing launch that adds them in a fixed order and STORES
-# the result: a process replays itself bit for bit (with CALCIUMGAN_AUTOTUNE=0 or
-# a loaded tile table also across processes), and no gradient buffer needs
+# the result: a process replays itself bit for bit (also across processes: the
+# static tile choice is the default), and no gradient buffer needs
 # zeroing.  CALCIUMGAN_DETERMINISTIC=0: the atomics (+= onto zeroed buffers).
 # (CALCIUMGAN_WGRAD_PARTIALS=0 brings cg_wgrad's atomics back: they add onto
 # zeroed gradients, so it switches the whole mode off)
@@ -136,6 +136,13 @@ def reduce_ws(device):
 _NARROW_LAST = __import__('os').environ.get('CALCIUMGAN_NARROW_LAST', '1') != '0'
 
 
+def narrow_last_rule(parity_major, CK, Cx, taps, C_real):
+  """Whether a packed operand's last 32-channel chunk is laid out narrow (one
+  8-channel group per tap): a 102-of-128 kind of pitch, parity-major weights."""
+  return bool(_NARROW_LAST and parity_major and CK == 32 and Cx >= 64 and
+              taps <= 32 and Cx - 32 < C_real <= Cx - 24)
+
+
 class PackedOperand(object):
   """bf16 MFMA operand of one (layer, direction), produced from the f32 master
   tensor by cg_pack_weights in the K order cg_swconv walks."""
@@ -149,9 +156,7 @@ class PackedOperand(object):
     # channel padding of the last 32-channel chunk (102 -> 128: 6 real
     # channels of 32): packed as ONE 8-channel group per tap, so a launch
     # walks 32 K groups of that chunk instead of taps * 4
-    self.narrow_last = bool(_NARROW_LAST and self.parity_major and CK == 32 and
-                            Cx >= 64 and taps <= 32 and
-                            Cx - 32 < C_real <= Cx - 24)
+    self.narrow_last = narrow_last_rule(self.parity_major, CK, Cx, taps, C_real)
     self.elems = lib.cg_packed_elems(N_real, taps, Cx, CK)
     if self.elems < 0:
       raise ValueError('bad packing geometry')
@@ -307,6 +312,11 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
   if rowsumsq is not None and DETERMINISTIC and x.is_cuda:
     # ordered penalty norm: one slot per workgroup of the chosen tile
     need = _lib.load().cg_rowsumsq_ws_elems(ctypes.byref(d))
+    if need <= 0:
+      # (never fall back to the atomics norm silently in ordered mode)
+      raise RuntimeError('calciumgan_amd: no ordered penalty-norm workspace for '
+                         'this launch (tile {}); CALCIUMGAN_DETERMINISTIC=0 '
+                         'selects the atomics form'.format(d.tile))
     if need > 0:
       wsq = torch.empty(need, dtype=torch.float32, device=x.device)
       d._keep = d._keep + (wsq,)
@@ -345,10 +355,13 @@ def _ln_fusable(lay, CK, taps):
 # per candidate, a few milliseconds in total) when its descriptor is first
 # built.  All candidates walk K in the same order; the 16x16x32 and 32x32x16
 # MFMA shapes may differ in the last f32 bit of a 32-deep partial sum, so a
-# process keeps ONE choice per geometry (and CALCIUMGAN_AUTOTUNE=0 pins the
-# static default for run-to-run bit reproducibility).
+# process keeps ONE choice per geometry.  Since round 5 the tuner is OPT-IN
+# (CALCIUMGAN_AUTOTUNE=1): the static choice below costs nothing measurable on the
+# whole step (profiles/r04_static_tiles_whole_step.txt: 12.67 / 12.81 ms static vs
+# 12.74 / 12.72 tuned) and makes every run -- bench.py, main.py, the tests --
+# replay bit for bit across processes.
 _TILE_CACHE = {}
-_AUTOTUNE = __import__('os').environ.get('CALCIUMGAN_AUTOTUNE', '1') != '0'
+_AUTOTUNE = __import__('os').environ.get('CALCIUMGAN_AUTOTUNE', '0') == '1'
 # CALCIUMGAN_TILE_CACHE=<file.json>: choices are loaded from / saved to this
 # file, so later processes (profiler passes, the other ranks' restarts) launch
 # exactly the tuned configuration without re-timing candidates.

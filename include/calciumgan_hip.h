@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 17
+#define CG_ABI_VERSION 18
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -97,6 +97,15 @@ int cg_tile_shape(int tile, int* rows, int* cols);
  * default (CALCIUMGAN_SWP_LEAN_EPI=1 turns them on at load): same results bit
  * for bit, no faster. */
 int cg_debug_lean_epilogue(int on);
+/* Form of cg_wgrad_batched for launches whose layers all take the ring-staged
+ * 24-tap kernel with `partials` (round 5, ABI 18): 0 the K'-split forms, 1
+ * (default; env CALCIUMGAN_WGRAD_FLEX) the flex form -- layers side by side,
+ * equal contiguous K' shares -- when every team's share is worth its set-up, 2
+ * the flex form whatever the size (tests).  Returns the previous mode; any
+ * other argument only reads it.  Results are identical on exactly representable
+ * data; in floating point the forms differ in summation order. */
+int cg_debug_wgrad_flex(int mode);
+
 int cg_profile_enable(int max_launches);
 int cg_profile_collect(float* ms, int* family, int capacity);
 
@@ -333,6 +342,14 @@ long long cg_wgrad_partials_elems(const cg_wgrad_desc* d);
  * the summation order differs); descriptors with `partials` are reduced by one
  * extra launch for all layers. */
 int cg_wgrad_batched(const cg_wgrad_desc* descs, int n, void* stream);
+/* The flex form's share plan for inspection (host only, nothing is launched):
+ * returns the number of ints of the table -- items [workgroups][8][6] = (layer
+ * or -1, bx, by, first K' tile, tiles, slot), then per layer [gx * gy][2] =
+ * (first slot, slots) -- and copies it to `out` when out_ints suffices; info
+ * (>= 16 ints): team size, teams, workgroups, items, slots of layer 0..5, int
+ * offsets of the layers' tile tables.  < 0: not the flex form under `mode`. */
+long long cg_wgrad_flex_plan(const cg_wgrad_desc* descs, int n, int mode, int* out,
+                             long long out_ints, int* info);
 
 /* Second half of cg_conv_desc.out_shifts: per sample with shift s,
  *   delta[b, r, :] = 0 for the |s| rows r no output row maps to, and

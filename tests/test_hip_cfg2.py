@@ -4,15 +4,15 @@ the committed oracle fixture tests/golden/wgan_gp_cfg2.npz (written by
 tests/make_golden_cfg2.py: f32 oracle and the oracle with bf16 storage
 emulated, same seeds for weights / inputs / draws).
 
-Launches use the tile table the benchmark was tuned to
-(profiles/r02_tuned_tiles.json: same launch geometries, since the batch is the
-benchmark's), so the kernels bench.py times are the kernels checked here.
+Launches use the static tile choice, which since round 5 is also what bench.py
+and main.py run by default (the tuner is opt-in, CALCIUMGAN_AUTOTUNE=1): same
+batch, same launch geometries, so the kernels bench.py times are the kernels
+checked here.
 
 Tolerances: forward values / losses 1e-2 against the emulating
 oracle, 3e-2 against f32; gradients per tensor by norm and by sampled elements
 (bars below, set from the measured bf16 noise floor of the emulation itself).
 """
-import glob
 import importlib.util
 import os
 
@@ -40,13 +40,11 @@ def _maker():
 @pytest.fixture(scope='module')
 def cfg2():
   """(maker module, golden arrays, hparams, gen, dis, gan, real): models hold
-  the fixture's initial weights; the benchmark's tile table is loaded."""
+  the fixture's initial weights; tiles are the static (default) choice."""
   from calciumgan_amd import nets
   from calciumgan_amd.gan.algorithms import get_algorithm
   from calciumgan_amd.gan.models import get_models
-  tables = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r??_tuned_tiles.json')))
-  if tables:
-    nets.load_tile_cache(tables[-1])
+  assert not nets._AUTOTUNE or os.environ.get('CALCIUMGAN_AUTOTUNE') == '1'
   M = _maker()
   gold = np.load(GOLDEN)
   hp, gw, dw, real = M.build()

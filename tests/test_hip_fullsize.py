@@ -300,3 +300,62 @@ def test_lean_epilogues_equal_the_classic_tiles_at_full_size(tile, nB, L, Ci, Co
   finally:
     nets._AUTOTUNE = nets_autotune
     _lib.load().cg_debug_lean_epilogue(was)
+
+
+def test_flex_weight_gradients_equal_the_split_form_at_full_size():
+  """cg_wgrad_batched over the critic's five layers at cfg2's full size (3 x 128
+  samples): the flex form (round 5: layers side by side, contiguous K' shares,
+  ~1.4 partial tiles per workgroup) against the K'-split form it replaces, on
+  small-integer data -- every partial sum is an integer below 2^24, so both forms
+  are exact and dW / dbias must be EQUAL bit for bit whatever the order of the
+  sums.  (a new store form is believed only after a full-size
+  bit-exact test; autodiff of calciumgan.py:145-185.)"""
+  import ctypes
+  lib = _lib.load()
+  gen = torch.Generator(device=H.DEV)
+  gen.manual_seed(77)
+  k, seg = 24, 128
+  descs = {0: [], 1: []}
+  outs = {0: [], 1: []}
+  keep = []
+  for li, (nB, L, Ci, Co) in enumerate(_CRITIC):
+    cip, cop = geo.pitch(Ci), geo.pitch(Co)
+    x = _pitched(_rand_int(gen, (nB, L, Ci), -2, 2), cip)
+    g = _pitched(_rand_int(gen, (nB, L // 2, Co), -1, 1), cop)
+    sh = torch.tensor([5, -9, 2], dtype=torch.int32, device=H.DEV)
+    keep += [x, g, sh]
+    for mode in (0, 1):
+      dw = torch.full((k, Ci, Co), 7.0, dtype=torch.float32, device=H.DEV)
+      db = torch.full((Co,), 7.0, dtype=torch.float32, device=H.DEV)
+      d = nets._wgrad_desc(x, g, dw, nB, L, cip, L // 2, cop, k, 2,
+                           -geo.same_padding_left(k, 2), Ci, Co,
+                           shifts=sh if li else None, seg_size=seg, dbias=db,
+                           bias_rows=2 * seg * (L // 2), slot=(mode, li))
+      assert d.partials and d.store
+      descs[mode].append(d)
+      outs[mode].append((dw, db))
+  was = lib.cg_debug_wgrad_flex(-1)
+  try:
+    for mode in (0, 1):
+      lib.cg_debug_wgrad_flex(mode)
+      arr = (_lib.WgradDesc * 5)(*descs[mode])
+      _lib.call('cg_wgrad_batched', arr, 5, H.stream())
+      H.sync()
+  finally:
+    lib.cg_debug_wgrad_flex(was)
+  # the flex form was taken (the plan exists at this size)
+  arr = (_lib.WgradDesc * 5)(*descs[1])
+  assert lib.cg_wgrad_flex_plan(arr, 5, 1, None, 0, None) > 0
+  for (dwa, dba), (dwb, dbb) in zip(outs[0], outs[1]):
+    assert float(dwa.abs().max()) > 7.0
+    assert torch.equal(dwa, dwb)
+    assert torch.equal(dba, dbb)
+  # and one layer against a torch contraction of the same operands (layer 5:
+  # small enough for an f64 einsum on the device)
+  nB, L, Ci, Co = _CRITIC[4]
+  x, g, sh = keep[12], keep[13], keep[14]
+  xs = _shuffled(x[:, :, :Ci].double(), [5, -9, 2], seg)
+  xp = torch.nn.functional.pad(xs, (0, 0, 11, 11))
+  ref = torch.stack([torch.einsum('bui,buo->io', xp[:, t:t + L:2], g[:, :, :Co].double())
+                     for t in range(k)])
+  assert torch.equal(outs[1][4][0].double(), ref)

@@ -93,40 +93,96 @@ ALL_TILES = ([(t, ks) for t in sorted(_lib.TILES) for ks in (2, 4)] +
 @pytest.fixture(params=[0, 1], ids=['generic_epi', 'lean_epi'])
 def epi_mode(request):
   """Both epilogue forms of the 32-row software-pipelined tiles: the run-time
-  one (default) and the specialised ones (cg_debug_lean_epilogue)."""
+  one (default) and the specialised ones (cg_debug_lean_epilogue).  Tests that
+  also sweep tiles parametrise it indirectly, with the specialised form only on
+  the tiles that have it (13 / 14 / 15)."""
   was = _lib.load().cg_debug_lean_epilogue(request.param)
   yield request.param
   _lib.load().cg_debug_lean_epilogue(was)
 
 
-def _lean_only_on(epi_mode, tile):
-  if epi_mode and tile not in (13, 14, 15):
-    pytest.skip('the specialised epilogues exist on tiles 13 / 14 / 15')
+LEAN_TILES = (13, 14, 15)
+_PH = torch.zeros(1)  # placeholder tensor of the collection-time descriptors
+
+
+def _admits(d, tile, ks, sp=0):
+  """cg_swconv_check (host only) of descriptor d on (tile, stage depth,
+  split-parity): the parametrisations below are built from it at collection
+  time, so only admissible combinations become test cases (405
+  run-time skips hid nothing, but would have hidden a real one)."""
+  d.tile, d.stage_ksteps, d.split_parity = tile, ks, sp
+  return _lib.load().cg_swconv_check(ctypes.byref(d)) == 0
 
 
 def _force_tile(d, tile, ks, sp=0):
-  """Override the autotuned choice; skip when the shape does not admit the
-  tile (cg_swconv answers CG_EINVAL and launches nothing)."""
+  """Override the static choice with an admissible (tile, stage depth,
+  split-parity): cg_swconv must accept it."""
   d.tile, d.stage_ksteps, d.split_parity = tile, ks, sp
-  rc = _lib.load().cg_swconv(ctypes.byref(d), H.stream())
-  if rc == _lib.CG_EINVAL:
-    pytest.skip('tile %d not admissible for this shape' % tile)
-  assert rc == 0
+  assert _lib.load().cg_swconv(ctypes.byref(d), H.stream()) == 0
 
 
-@pytest.mark.parametrize('sp', [0, 1])
-@pytest.mark.parametrize('tile,ks', ALL_TILES)
-@pytest.mark.parametrize('nB,L,Ci,Co,k,seg', [(2, 1024, 64, 192, 24, 1),
-                                              (6, 128, 96, 102, 24, 2),
-                                              (3, 512, 32, 64, 8, 3),
-                                              (3, 1024, 102, 64, 24, 2),
-                                              (4, 64, 70, 40, 8, 4)])
+def _fwd_desc(xd, wbuf, y, nB, L, Ci, Co, k, sp, **kw):
+  """Descriptor of the stride-2 forward tests (device tensors, or _PH at
+  collection time)."""
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  Lo = L // 2
+  ck = nets._ck_for(cip, 2, k, Lo)
+  return H.conv_desc(xd, wbuf, y, nB, L, cip, k, 2, -geo.same_padding_left(k, 2),
+                     Lo, Co, Lo, cop, ck, w_parity_major=bool(sp),
+                     w_narrow_last=nets.narrow_last_rule(bool(sp), ck, cip, k, Ci),
+                     **kw)
+
+
+def _dgrad_desc(dyd, wbuf, y, nB, L, Ci, Co, k, **kw):
+  """Two-phase transposed convolution (input gradient of a stride-2 conv)."""
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  offs = [o for _, o in nets._transpose_phases(k, geo.same_padding_left(k, 2))]
+  ck = nets._ck_for(cop, 1, k // 2, L // 2)
+  elems = _lib.load().cg_packed_elems(Ci, k // 2, cop, ck)
+  return H.conv_desc(dyd, wbuf, y, nB, L // 2, cop, k // 2, 1, offs[0], L // 2,
+                     Ci, L, cip, ck, y_stride=2, y_off=0, nphase=2,
+                     w_phase_stride=elems, off_phase_step=offs[1] - offs[0],
+                     yoff_phase_step=1, **kw)
+
+
+def _tile_cases(shapes, admit, sps=(0,), tiles=None):
+  """pytest params (tile, ks, *shape, sp, epi_mode) for every admissible
+  combination; epi_mode 1 (specialised epilogues) only on LEAN_TILES."""
+  out = []
+  for shape in shapes:
+    for tile, ks in (tiles or ALL_TILES):
+      for sp in sps:
+        if not admit(tile, ks, sp, *shape):
+          continue
+        for em in (0, 1):
+          if em and tile not in LEAN_TILES:
+            continue
+          out.append(pytest.param(
+              tile, ks, *shape, sp, em,
+              id='t{}k{}-{}-sp{}-{}'.format(tile, ks, 'x'.join(map(str, shape)), sp,
+                                            'lean' if em else 'generic')))
+  return out
+
+
+FWD_SHAPES = [(2, 1024, 64, 192, 24, 1), (6, 128, 96, 102, 24, 2),
+              (3, 512, 32, 64, 8, 3), (3, 1024, 102, 64, 24, 2),
+              (4, 64, 70, 40, 8, 4)]
+
+
+def _fwd_admits(tile, ks, sp, nB, L, Ci, Co, k, seg):
+  d = _fwd_desc(_PH, _PH, _PH, nB, L, Ci, Co, k, sp, bias=_PH, shifts=_PH,
+                seg_size=seg, epilogue=_lib.EPI_LRELU)
+  return _admits(d, tile, ks, sp)
+
+
+@pytest.mark.parametrize('tile,ks,nB,L,Ci,Co,k,seg,sp,epi_mode',
+                         _tile_cases(FWD_SHAPES, _fwd_admits, sps=(0, 1)),
+                         indirect=['epi_mode'])
 def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp, epi_mode):
   """Stride-2 forward with phase shuffle + bias + LeakyReLU on every workgroup
   tile (both MFMA shapes, 4x1 and 2x2 waves) and both weight-stage depths,
   including partial column tiles (192, 102) and several samples per tile;
   sp = 1: parity-major weights with split-parity window staging."""
-  _lean_only_on(epi_mode, tile)
   rng = np.random.RandomState(2)
   x = H.int_tensor(rng, (nB, L, Ci))
   W = H.int_tensor(rng, (k, Ci, Co), -2, 2, 0.5)
@@ -157,7 +213,7 @@ def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp, epi_mode):
   np.testing.assert_array_equal(got[:, :, :Co].numpy(), ref.numpy())
   if cop > Co:
     assert float(got[:, :, Co:].abs().max()) == 0.0
-  if sp:
+  if sp and _admits(d, tile, ks, 0):
     # the same parity-major (and narrow) operand with both parities resident
     y.fill_(7.0)
     _force_tile(d, tile, ks, 0)
@@ -166,17 +222,24 @@ def test_conv_fwd_every_tile(tile, ks, nB, L, Ci, Co, k, seg, sp, epi_mode):
                                   ref.numpy())
 
 
-@pytest.mark.parametrize('epi', [_lib.EPI_NONE, _lib.EPI_MASK])
-@pytest.mark.parametrize('tile', sorted(_lib.SWP_TILES))
-@pytest.mark.parametrize('nB,L,Ci,Co,k', [(5, 512, 102, 64, 24),
-                                          (3, 128, 64, 128, 24)])
-def test_conv_fwd_row_scale(tile, nB, L, Ci, Co, k, epi, epi_mode):
+def _row_scale_admits(tile, ks, sp, nB, L, Ci, Co, k, epi):
+  d = _fwd_desc(_PH, _PH, _PH, nB, L, Ci, Co, k, 1, bias=_PH, epilogue=epi,
+                mask_src=_PH if epi == _lib.EPI_MASK else None, row_scale=_PH)
+  return _admits(d, tile, ks, 0)
+
+
+@pytest.mark.parametrize(
+    'tile,ks,nB,L,Ci,Co,k,epi,sp,epi_mode',
+    _tile_cases([(5, 512, 102, 64, 24, e) for e in (_lib.EPI_NONE, _lib.EPI_MASK)] +
+                [(3, 128, 64, 128, 24, e) for e in (_lib.EPI_NONE, _lib.EPI_MASK)],
+                _row_scale_admits, tiles=[(t, 2) for t in sorted(_lib.SWP_TILES)]),
+    indirect=['epi_mode'])
+def test_conv_fwd_row_scale(tile, ks, nB, L, Ci, Co, k, epi, sp, epi_mode):
   """cg_conv_desc.row_scale: y = epi((acc + bias) * row_scale[sample]) on the
   software-pipelined tiles -- the penalty's v = coef_b * g folded into the
   tangent chain's first launch.  Power-of-two scales on small-integer data:
   bit-exact against the convolution of the pre-scaled input; the classic tiles,
   split-K and the fused LayerNorm refuse the field."""
-  _lean_only_on(epi_mode, tile)
   rng = np.random.RandomState(11)
   x = H.int_tensor(rng, (nB, L, Ci))
   W = H.int_tensor(rng, (k, Ci, Co), -2, 2, 0.5)
@@ -216,12 +279,26 @@ def test_conv_fwd_row_scale(tile, nB, L, Ci, Co, k, epi, epi_mode):
   assert lib.cg_swconv(ctypes.byref(d), H.stream()) == _lib.CG_EINVAL
 
 
-@pytest.mark.parametrize('ksplit', [2, 4])
-@pytest.mark.parametrize('tile', [0, 1, 2, 4, 8, 9, 10, 11, 12, 13, 14, 15])
-@pytest.mark.parametrize('nB,L,Ci,Co,k,epi', [(3, 256, 128, 192, 24, 1),
-                                              (2, 128, 102, 64, 24, 2),
-                                              (4, 64, 256, 320, 24, 0),
-                                              (2, 512, 256, 128, 24, 2)])
+def _split_k_cases():
+  out = []
+  for nB, L, Ci, Co, k, epi in [(3, 256, 128, 192, 24, 1), (2, 128, 102, 64, 24, 2),
+                                (4, 64, 256, 320, 24, 0), (2, 512, 256, 128, 24, 2)]:
+    cip = geo.pitch(Ci)
+    ck = nets._ck_for(cip, 2, k, L // 2)
+    for tile in [0, 1, 2, 4, 8, 9, 10, 11, 12, 13, 14, 15]:
+      for ksplit in (2, 4):
+        if (cip // ck) % ksplit:
+          continue
+        d = _fwd_desc(_PH, _PH, _PH, nB, L, Ci, Co, k, 1,
+                      bias=_PH if epi == 1 else None, shifts=_PH, seg_size=1,
+                      epilogue=epi, mask_src=_PH if epi == 2 else None)
+        d.ksplit, d.split_ws, d.split_ws_elems = ksplit, _PH.data_ptr(), 1 << 40
+        if _admits(d, tile, 2, 0):
+          out.append((tile, ksplit, nB, L, Ci, Co, k, epi))
+  return out
+
+
+@pytest.mark.parametrize('tile,ksplit,nB,L,Ci,Co,k,epi', _split_k_cases())
 def test_conv_fwd_split_k(tile, ksplit, nB, L, Ci, Co, k, epi):
   """cg_conv_desc.ksplit: several workgroups per output tile, each over a share
   of the channel chunks, f32 partial sums + a finishing launch (bias /
@@ -240,8 +317,6 @@ def test_conv_fwd_split_k(tile, ksplit, nB, L, Ci, Co, k, epi):
   Lo = L // 2
   pl = geo.same_padding_left(k, 2)
   ck = nets._ck_for(cip, 2, k, Lo)
-  if (cip // ck) % ksplit:
-    pytest.skip('channel chunks do not divide')
   op = H.pack(W.to(H.DEV), [(0, 1, Ci * Co, Co, 1)], Ci, Co, cip, ck, k,
               parity_major=True)
   y = torch.full((nB, Lo, cop), 7.0, dtype=BF16, device=H.DEV)
@@ -270,13 +345,20 @@ def test_conv_fwd_split_k(tile, ksplit, nB, L, Ci, Co, k, epi):
     assert float(got[:, :, Co:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('tile,ks', ALL_TILES)
-@pytest.mark.parametrize('nB,L,Ci,Co,k', [(2, 512, 102, 128, 24),
-                                          (5, 128, 192, 256, 24)])
-def test_conv_dgrad_every_tile(tile, ks, nB, L, Ci, Co, k, epi_mode):
+def _dgrad_admits(tile, ks, sp, nB, L, Ci, Co, k):
+  d = _dgrad_desc(_PH, _PH, _PH, nB, L, Ci, Co, k, out_f32=True)
+  if L // 2 >= _lib.tile_shape(tile)[0]:
+    d.rowsumsq = _PH.data_ptr()
+  return _admits(d, tile, ks, 0)
+
+
+@pytest.mark.parametrize('tile,ks,nB,L,Ci,Co,k,sp,epi_mode',
+                         _tile_cases([(2, 512, 102, 128, 24), (5, 128, 192, 256, 24)],
+                                     _dgrad_admits),
+                         indirect=['epi_mode'])
+def test_conv_dgrad_every_tile(tile, ks, nB, L, Ci, Co, k, sp, epi_mode):
   """Two-phase transposed convolution (f32 out, strided rows) + the fused
   per-sample sum of squares on every tile."""
-  _lean_only_on(epi_mode, tile)
   rng = np.random.RandomState(3)
   W = H.int_tensor(rng, (k, Ci, Co), -1, 1, 0.5)
   dy = H.int_tensor(rng, (nB, L // 2, Co), -2, 2)
@@ -392,20 +474,39 @@ def test_conv_transpose_fwd_bitexact(B, L, Ci, Co, k):
   np.testing.assert_array_equal(y.cpu()[:, :, :Co].numpy(), ref.numpy())
 
 
-@pytest.mark.parametrize('tile,ks', [(5, 2), (5, 4), (6, 2), (6, 4), (7, 2),
-                                     (7, 4), (8, 2), (8, 4), (11, 2), (12, 2), (15, 2)])
-@pytest.mark.parametrize('B,L,Ci,Co,k', [(3, 256, 128, 102, 24),
-                                          (2, 512, 192, 128, 24),
-                                          (5, 16, 64, 40, 24),
-                                          (2, 4, 32, 6, 8)])
+def _ln_desc(xd, wbuf, y, B, L, Ci, Co, k, **kw):
+  """Conv1DTranspose forward (two 12-tap phases) of the fused-LayerNorm test."""
+  cip, cop = geo.pitch(Ci), geo.pitch(Co)
+  offs = [o for _, o in nets._transpose_phases(k, geo.same_padding_left(k, 2))]
+  ck = nets._ck_for(cip, 1, k // 2, L)
+  elems = _lib.load().cg_packed_elems(Co, k // 2, cip, ck)
+  return H.conv_desc(xd, wbuf, y, B, L, cip, k // 2, 1, offs[0], L, Co, 2 * L,
+                     cop, ck, y_stride=2, nphase=2, w_phase_stride=elems,
+                     off_phase_step=offs[1] - offs[0], yoff_phase_step=1, **kw)
+
+
+def _ln_cases():
+  out = []
+  for B, L, Ci, Co, k in [(3, 256, 128, 102, 24), (2, 512, 192, 128, 24),
+                          (5, 16, 64, 40, 24), (2, 4, 32, 6, 8)]:
+    for tile, ks in [(5, 2), (5, 4), (6, 2), (6, 4), (7, 2), (7, 4), (8, 2),
+                     (8, 4), (11, 2), (12, 2), (15, 2)]:
+      tm = _lib.tile_shape(tile)[0]
+      if not ((L % tm == 0) if L >= tm else (tm % L == 0)):
+        continue
+      d = _ln_desc(_PH, _PH, _PH, B, L, Ci, Co, k, bias=_PH,
+                   ln=(_PH, _PH, _PH, _PH, _PH))
+      if _admits(d, tile, ks):
+        out.append((tile, ks, B, L, Ci, Co, k))
+  return out
+
+
+@pytest.mark.parametrize('tile,ks,B,L,Ci,Co,k', _ln_cases())
 def test_conv_transpose_layernorm_fused(tile, ks, B, L, Ci, Co, k):
   """Conv1DTranspose + LayerNormalization + LeakyReLU (calciumgan.py:61-70) in
   one launch == the same launch without the fusion followed by the separate
   cg_ln_lrelu_fwd pass: the stored pre-activation bit for bit, the statistics
   and the activation to rounding."""
-  tm = _lib.tile_shape(tile)[0]
-  if not ((L % tm == 0) if L >= tm else (tm % L == 0)):
-    pytest.skip('row tile does not divide this length')
   rng = np.random.RandomState(21)
   x = torch.tensor(rng.randn(B, L, Ci).astype(np.float32))
   Wt = torch.tensor(rng.randn(k, 1, Co, Ci).astype(np.float32) * 0.05)
@@ -436,8 +537,7 @@ def test_conv_transpose_layernorm_fused(tile, ks, B, L, Ci, Co, k):
   d1 = H.conv_desc(xd, op.buf, y1, B, L, cip, k // 2, 1, offs[0], L, Co, 2 * L,
                    cop, ck, ln=(gam, bet, h1, m1, r1), **common)
   d1.tile, d1.stage_ksteps = tile, ks
-  if _lib.load().cg_swconv_check(ctypes.byref(d1)) == _lib.CG_EINVAL:
-    pytest.skip('tile %d not admissible for this shape' % tile)
+  assert _lib.load().cg_swconv_check(ctypes.byref(d1)) == 0
   H.run_conv(d1)
   # forward-only form (no statistics buffers): same activation, y not written
   y2 = torch.full((B, 2 * L, cop), 5.0, dtype=BF16, device=H.DEV)
@@ -638,9 +738,30 @@ WGRAD_CASES = [
 ]
 
 
-@pytest.mark.parametrize('classic', [0, 1])
-@pytest.mark.parametrize('partials', [False, True])
-@pytest.mark.parametrize('nB,L,Ci,Co,k,seg,use_shift', WGRAD_CASES)
+def _wgrad_test_desc(x, g, dw, nB, L, Ci, Co, k, **kw):
+  return nets._wgrad_desc(x, g, dw, nB, L, geo.pitch(Ci), L // 2, geo.pitch(Co), k,
+                          2, -geo.same_padding_left(k, 2), Ci, Co, **kw)
+
+
+def _wgrad_cases():
+  """(case, partials, classic); the partial-sum form only where three K' splits
+  exist at the shape."""
+  out = []
+  for case in WGRAD_CASES:
+    nB, L, Ci, Co, k, seg, use_shift = case
+    for partials in (False, True):
+      for classic in (0, 1):
+        if partials:
+          d = _wgrad_test_desc(_PH, _PH, _PH, nB, L, Ci, Co, k, seg_size=seg)
+          d.classic_staging, d.nsplit = classic, 3
+          if _lib.load().cg_wgrad_partials_elems(ctypes.byref(d)) <= 0:
+            continue
+        out.append(case + (partials, classic))
+  return out
+
+
+@pytest.mark.parametrize('nB,L,Ci,Co,k,seg,use_shift,partials,classic',
+                         _wgrad_cases())
 def test_conv_wgrad_bitexact(nB, L, Ci, Co, k, seg, use_shift, partials, classic):
   """partials = True: the K' splits store partial sums that a second launch
   adds into dw (which must ACCUMULATE: dw starts at 1); False: f32 atomics.
@@ -670,8 +791,7 @@ def test_conv_wgrad_bitexact(nB, L, Ci, Co, k, seg, use_shift, partials, classic
   if partials:
     d.nsplit = 3  # several K' splits whatever the shape
     need = _lib.load().cg_wgrad_partials_elems(ctypes.byref(d))
-    if need <= 0:
-      pytest.skip('single K\' split at this shape')
+    assert need > 0
     ws = torch.full((need,), float('nan'), device=H.DEV)
     d.partials, d.partials_elems = ws.data_ptr(), need
   H.run_wgrad(d)
@@ -1085,7 +1205,16 @@ def test_adam_colsum_sigmoid_lrelu_metrics():
     np.testing.assert_allclose(got, exp, rtol=1e-4)
 
 
-def test_wgrad_batched_equals_individual_launches():
+@pytest.fixture(params=[0, 2], ids=['split_forms', 'flex'])
+def wgrad_form(request):
+  """cg_wgrad_batched's K'-split forms (plain / halves) and the flex form
+  (forced: the small test shapes would otherwise take the split forms)."""
+  was = _lib.load().cg_debug_wgrad_flex(request.param)
+  yield request.param
+  _lib.load().cg_debug_wgrad_flex(was)
+
+
+def test_wgrad_batched_equals_individual_launches(wgrad_form):
   """cg_wgrad_batched (one launch over several layers) accumulates exactly
   what the per-layer launches do; a batch that cannot be fused (a 1-tap Dense
   gradient among them) falls back to individual launches."""
@@ -1111,6 +1240,9 @@ def test_wgrad_batched_equals_individual_launches():
   for d in descs_a:
     H.run_wgrad(d)
   arr = (_lib.WgradDesc * len(descs_b))(*descs_b)
+  # (the flex form plans at this size only when forced: mode 2)
+  planned = _lib.load().cg_wgrad_flex_plan(arr, len(descs_b), 2, None, 0, None) > 0
+  assert planned
   _lib.call('cg_wgrad_batched', arr, len(descs_b), H.stream())
   H.sync()
   for (dwa, dba), (dwb, dbb) in zip(outs_a, outs_b):
