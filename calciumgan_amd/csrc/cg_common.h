@@ -144,6 +144,26 @@ __device__ __forceinline__ float group_sum_n(float v, int n) {
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum_n(v, 64); }
+// min / max over aligned groups of n lanes, the same DPP / permlane pairings
+// (__shfl_xor is ds_bpermute_b32: an LDS-pipe round trip per step)
+__device__ __forceinline__ float group_max_n(float v, int n) {
+  if (n > 1) v = fmaxf(v, dpp_partner<0xB1>(v));
+  if (n > 2) v = fmaxf(v, dpp_partner<0x4E>(v));
+  if (n > 4) v = fmaxf(v, dpp_partner<0x141>(v));
+  if (n > 8) v = fmaxf(v, dpp_partner<0x140>(v));
+  if (n > 16) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v),
+                                                     false, false);
+    v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  }
+  if (n > 32) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v),
+                                                     false, false);
+    v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  }
+  return v;
+}
+__device__ __forceinline__ float group_min_n(float v, int n) { return -group_max_n(-v, n); }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

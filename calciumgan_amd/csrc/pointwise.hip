@@ -206,6 +206,100 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(
   }
 }
 
+// Rows whose 8-channel groups are not a power of two (320 -> 40 groups, 192 ->
+// 24) left 37 / 25 % of the lanes of ln_fwd_kernel idle (64 / 32 lanes per row:
+// 3.97 TB/s on the generator's 320- and 192-channel blocks).  Here a row is
+// always 8 lanes, each holding GPL groups (lane j takes groups j, j + 8, ...: a
+// load instruction covers 128 contiguous bytes per row), so every lane works
+// for any pitch that is a multiple of 64 channels and a wave carries 8 rows.
+// Gamma / beta live in LDS (GPL x 16 registers otherwise).
+template <int GPL>
+__global__ __launch_bounds__(kThreads) void ln_fwd8_kernel(
+    const uint16_t* __restrict__ y, const float* __restrict__ gamma,
+    const float* __restrict__ beta, uint16_t* __restrict__ h,
+    float* __restrict__ mean_o, float* __restrict__ rstd_o, long long rows,
+    int C, int Cp, float eps, float alpha, int rows_per_slot) {
+  __shared__ float sgam[GPL * 64], sbet[GPL * 64];
+  for (int i = threadIdx.x; i < GPL * 64; i += kThreads) {
+    sgam[i] = i < C ? gamma[i] : 0.f;
+    sbet[i] = i < C ? beta[i] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;
+  const int slot = lane >> 3;
+  constexpr int rpw = 8;
+  const long long wave_id =
+      (long long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const int ng = Cp >> 3;
+  const float invC = 1.f / C;
+  const long long row0 = wave_id * (long long)rpw * rows_per_slot + slot;
+  constexpr int kRB = 2;
+  for (int it0 = 0; it0 < rows_per_slot; it0 += kRB) {
+    uint4 raw[kRB][GPL];
+#pragma unroll
+    for (int k = 0; k < kRB; ++k) {
+      const long long row = row0 + (long long)(it0 + k) * rpw;
+#pragma unroll
+      for (int j = 0; j < GPL; ++j) {
+        const int g = j * 8 + sub;
+        raw[k][j] = (row < rows && g < ng) ? ldg16(y + row * Cp + g * 8)
+                                           : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kRB; ++k) {
+      const long long row = row0 + (long long)(it0 + k) * rpw;
+      const bool rv = row < rows;  // uniform inside the 8-lane group
+      float v[GPL][8];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < GPL; ++j) {
+        unpack8(raw[k][j], v[j]);
+        const int c0 = (j * 8 + sub) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (c0 + e < C) s += v[j][e];
+      }
+      const float mean = group_sum_n(s, 8) * invC;
+      float s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < GPL; ++j) {
+        const int c0 = (j * 8 + sub) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (c0 + e < C) {
+            const float d = v[j][e] - mean;
+            s2 += d * d;
+          }
+      }
+      const float rstd = rsqrtf(group_sum_n(s2, 8) * invC + eps);
+      if (rv && sub == 0) {
+        if (mean_o) mean_o[row] = mean;
+        if (rstd_o) rstd_o[row] = rstd;
+      }
+      if (!rv) continue;
+#pragma unroll
+      for (int j = 0; j < GPL; ++j) {
+        const int g = j * 8 + sub;
+        if (g >= ng) continue;
+        const int c0 = g * 8;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = 0.f;
+          if (c0 + e < C) {
+            t = (v[j][e] - mean) * rstd * sgam[c0 + e] + sbet[c0 + e];
+            t = t > 0.f ? t : alpha * t;
+          }
+          o[e] = t;
+        }
+        store8(h + row * Cp + c0, o);
+      }
+    }
+  }
+}
+
 // dy = rstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)), dyh = do * gamma,
 // do = dh * lrelu'(h); dgamma += do * xhat, dbeta += do: per-lane partials ->
 // a fixed-order sum inside the block -> one partial row per block (ws; summed by
@@ -356,6 +450,13 @@ __global__ __launch_bounds__(kThreads) void bn_sums_kernel(
   float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (rl < rlanes) {
     float mu[8], rs[8];
+    if (MODE == 0) {
+      // statistics: sums of (y - K) and (y - K)^2 around the block's own first
+      // row K (the one-pass E[y^2] - E[y]^2 over raw values cancels for
+      // channels whose mean is large against their spread); bn_stats_finish_kernel
+      // combines the blocks' (count, mean, M2) -- tf.nn.moments' mean((y - mean)^2)
+      load8(y + (long long)blockIdx.x * rows_per_block * Cp + grp * 8, mu);
+    }
     if (MODE == 1) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -373,8 +474,9 @@ __global__ __launch_bounds__(kThreads) void bn_sums_kernel(
       if (MODE == 0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          a1[e] += vy[e];
-          a2[e] += vy[e] * vy[e];
+          const float d = vy[e] - mu[e];
+          a1[e] += d;
+          a2[e] += d * d;
         }
       } else {
         float vd[8], vh[8];
@@ -401,41 +503,67 @@ __global__ __launch_bounds__(kThreads) void bn_sums_kernel(
       t1 += s1[r * Cp + c];
       t2 += s2[r * Cp + c];
     }
-    float* row = ws + (long long)blockIdx.x * 2 * Cp;
+    float* row = ws + (long long)blockIdx.x * (MODE == 0 ? 3 : 2) * Cp;
     row[c] = t1;
     row[Cp + c] = t2;
+    if (MODE == 0)  // the block's shift (its first row)
+      row[2 * Cp + c] = act2f(y[(long long)blockIdx.x * rows_per_block * Cp + c]);
   }
 }
 
 // mean / biased variance from the partial rows (64 channels x 16 row classes per
 // block, as finish_cols_kernel) and the moving averages of the layer
+// Partial rows [3][Cp] per block: S1 = sum(y - K), S2 = sum((y - K)^2), K.  The
+// blocks' (count, mean, M2) are combined in a fixed order (16 row classes through
+// LDS, classes added in order): mean first, then M2 = sum(M2_b + n_b (mean_b -
+// mean)^2) -- the biased batch variance mean((y - mean)^2) of tf.nn.moments.
 __global__ __launch_bounds__(1024) void bn_stats_finish_kernel(
-    const float* __restrict__ ws, int nparts, int C, int Cp, float inv_rows,
-    float* __restrict__ mean, float* __restrict__ var,
+    const float* __restrict__ ws, int nparts, int C, int Cp, long long rows,
+    int rows_per_block, float* __restrict__ mean, float* __restrict__ var,
     float* __restrict__ moving_mean, float* __restrict__ moving_var,
     float momentum) {
-  __shared__ float sm[2][16][64];
+  __shared__ float sm[16][64];
+  __shared__ float smean[64];
   const int lane = threadIdx.x & 63;
   const int j = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
-  float a = 0.f, b = 0.f;
+  const float inv_rows = 1.f / (float)rows;
+  auto count = [&](int r) {
+    const long long left = rows - (long long)r * rows_per_block;
+    return (float)(left < rows_per_block ? left : rows_per_block);
+  };
+  float a = 0.f;
   if (c < Cp)
     for (int r = j; r < nparts; r += 16) {
-      a += ws[(long long)r * 2 * Cp + c];
-      b += ws[(long long)r * 2 * Cp + Cp + c];
+      const float* row = ws + (long long)r * 3 * Cp;
+      a += row[c] + count(r) * row[2 * Cp + c];  // the block's sum of y
     }
-  sm[0][j][lane] = a;
-  sm[1][j][lane] = b;
+  sm[j][lane] = a;
+  __syncthreads();
+  if (j == 0) {
+    float t = sm[0][lane];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sm[k][lane];
+    smean[lane] = t * inv_rows;
+  }
+  __syncthreads();
+  const float m = smean[lane];
+  float b = 0.f;
+  if (c < Cp)
+    for (int r = j; r < nparts; r += 16) {
+      const float* row = ws + (long long)r * 3 * Cp;
+      const float nb = count(r);
+      const float s1 = row[c];
+      const float d = row[2 * Cp + c] + s1 / nb - m;
+      b += (row[Cp + c] - s1 * s1 / nb) + nb * d * d;
+    }
+  sm[j][lane] = b;
   __syncthreads();
   if (j == 0 && c < C) {
-    float t1 = sm[0][0][lane], t2 = sm[1][0][lane];
+    float t2 = sm[0][lane];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) {
-      t1 += sm[0][k][lane];
-      t2 += sm[1][k][lane];
-    }
-    const float m = t1 * inv_rows;
-    const float v = fmaxf(t2 * inv_rows - m * m, 0.f);
+    for (int k = 1; k < 16; ++k) t2 += sm[k][lane];
+    const float v = fmaxf(t2 * inv_rows, 0.f);
     mean[c] = m;
     var[c] = v;
     if (moving_mean) {
@@ -1112,10 +1240,8 @@ __global__ __launch_bounds__(kThreads) void signal_metrics_kernel(
             mx = ok ? fmaxf(mx, t[e]) : mx;
             sum += t[e];
           }
-          for (int o = lpr >> 1; o > 0; o >>= 1) {
-            mn = fminf(mn, __shfl_xor(mn, o, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-          }
+          mn = group_min_n(mn, lpr);
+          mx = group_max_n(mx, lpr);
           const float mean = group_sum(sum, lpr) * invC;
           float s2 = 0.f;
 #pragma unroll
@@ -1246,6 +1372,25 @@ extern "C" int cg_ln_lrelu_fwd(const void* y_pre, const float* gamma,
 #define CG_LN_RPS_LO 4
 #define CG_LN_RPS_HI 8
 #endif
+  static const bool pow2_only = getenv("CALCIUMGAN_LN_POW2") != nullptr;  // (A/B)
+  if (lpr * 8 != Cp && Cp >= 64 && !pow2_only) {
+    // a pitch whose 8-channel groups are not a power of two: 8 lanes per row
+    const int gpl = (Cp / 8 + 7) / 8;
+    const int rps = rows_per_slot_for(rows, 8, 2, 8);
+    const dim3 grid(grid1d(rows, 4 * 8 * rps, 1LL << 31));
+#define CG_LN8(G)                                                                 \
+  case G:                                                                         \
+    hipLaunchKernelGGL(ln_fwd8_kernel<G>, grid, dim3(kThreads), 0, S_(stream),    \
+                       U16(y_pre), gamma, beta, U16W(h), mean, rstd, rows, C, Cp, \
+                       eps, alpha, rps);                                          \
+    break;
+    switch (gpl) {
+      CG_LN8(2) CG_LN8(3) CG_LN8(4) CG_LN8(5) CG_LN8(6) CG_LN8(7) CG_LN8(8)
+      default: return CG_EINVAL;
+    }
+#undef CG_LN8
+    CG_LAUNCH_CHECK();
+  }
   const int rows_per_slot = rows_per_slot_for(rows, rpw, CG_LN_RPS_LO, CG_LN_RPS_HI);
   hipLaunchKernelGGL(ln_fwd_kernel,
                      dim3(grid1d(rows, 4 * rpw * rows_per_slot, 1LL << 31)),
@@ -1300,7 +1445,7 @@ static int bn_rows_per_block(long long rows, int Cp) {
   int rpb = 256;
   while (rpb < 4096 && rows / (rpb * 2) >= 512) rpb *= 2;
   while ((rows + rpb - 1) / rpb > kMaxParts ||
-         ((rows + rpb - 1) / rpb) * 2ll * Cp > kReduceWsElems)
+         ((rows + rpb - 1) / rpb) * 3ll * Cp > kReduceWsElems)
     rpb *= 2;
   return rpb;
 }
@@ -1319,8 +1464,8 @@ extern "C" int cg_bn_stats(const void* y, long long rows, int C, int Cp,
                      (const uint16_t*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, rows, C, Cp, rpb, 0.f, 1.f, 0, ws);
   hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((Cp + 63) / 64), dim3(1024), 0,
-                     S_(stream), ws, (int)blocks, C, Cp, 1.f / (float)rows, mean,
-                     var, moving_mean, moving_var, momentum);
+                     S_(stream), ws, (int)blocks, C, Cp, rows, rpb, mean, var,
+                     moving_mean, moving_var, momentum);
   CG_LAUNCH_CHECK();
 }
 

@@ -1106,6 +1106,31 @@ extern "C" int cg_swconv_check(const cg_conv_desc* d) {
   return rc;
 }
 
+// CALCIUMGAN_LAUNCH_LOG=<file> (diagnostics: tools/traffic_by_geometry.sh): one
+// line per cg_swconv launch, in launch order, with the geometry that decides its
+// algorithmic bytes -- joined with the per-dispatch PMC rows of a profiled eager
+// run to attribute HBM traffic to launch geometries.
+static FILE* launch_log() {
+  static FILE* f = [] {
+    const char* p = getenv("CALCIUMGAN_LAUNCH_LOG");
+    return p && *p ? fopen(p, "a") : (FILE*)nullptr;
+  }();
+  return f;
+}
+static void log_launch(const cg_conv_desc* d) {
+  FILE* f = launch_log();
+  if (!f) return;
+  fprintf(f, "swconv stride=%d taps=%d nB=%d Lx=%d Cx=%d Lu=%d N=%d Ly=%d Cy=%d CK=%d "
+          "nphase=%d epi=%d f32=%d tile=%d ksplit=%d narrow=%d mask=%d shifts=%d "
+          "oshifts=%d ln=%d ssq=%d rscale=%d ystride=%d sp=%d\n",
+          d->stride, d->taps, d->nB, d->Lx, d->Cx, d->Lu, d->N, d->Ly, d->Cy, d->CK,
+          d->nphase, d->epilogue, d->out_f32, d->tile, d->ksplit > 1 ? d->ksplit : 1,
+          d->w_narrow_last, d->mask_src ? 1 : 0, d->shifts ? 1 : 0,
+          d->out_shifts ? 1 : 0, d->ln_gamma ? (d->ln_mean ? 2 : 1) : 0,
+          d->rowsumsq ? 1 : 0, d->row_scale ? 1 : 0, d->y_stride, d->split_parity);
+  fflush(f);
+}
+
 static int swconv_run(const cg_conv_desc* d, void* stream) {
   if (!d || !d->x || !d->w || !d->y) return CG_EINVAL;
   if (d->stride != 1 && d->stride != 2) return CG_EINVAL;
@@ -1231,6 +1256,7 @@ static int swconv_run(const cg_conv_desc* d, void* stream) {
     a.gm = (a.M + TM - 1) / TM;
     a.gn = (d->N + TN - 1) / TN;
     a.gp = d->nphase;
+    if (!g_dry_run) log_launch(d);
     const int rc = swconv_swp_launch(a, R, tc.swp_wm, tc.wgn, tc.mt, a.ksplit,
                                      g_dry_run, (hipStream_t)stream);
     if (rc || a.ksplit == 1 || g_dry_run) return ssq_finish(rc);
@@ -1261,6 +1287,7 @@ static int swconv_run(const cg_conv_desc* d, void* stream) {
   dim3 grid((unsigned)(((a.gm + 7) / 8) * 8 * a.gn * a.gp), (unsigned)a.ksplit);
   hipStream_t s = (hipStream_t)stream;
   int rc = CG_EINVAL;
+  if (!g_dry_run) log_launch(d);
   hipEvent_t split_start = nullptr, split_stop = nullptr;
   const bool split_timed =
       !g_dry_run && a.ksplit > 1 &&

@@ -60,6 +60,18 @@ struct SwpArgs {
   int ntl;           // linear tile ids: gm rounded up to 8, x gn x gp
   int bias_off;      // byte offset of the bias table in LDS (gn * TN floats)
   float inv_WRs;
+  // stride 2: the order of a tile's full passes.  Two 32-channel chunks share
+  // every 128-byte line of a source row.  0: (chunk, parity), parity innermost --
+  // the second half of a line is fetched TWO passes after the first, ~4.4 MB of
+  // window lines per XCD later: gone from the 4 MB L2, and the critic's first
+  // layer read its source 1.85 x (profiles/r05_swconv_traffic_by_geometry.txt).
+  // 1 (default): by LINE -- the pair of chunks that share a line, then parity, then
+  // the chunk of the pair: (c0,p0) (c1,p0) (c0,p1) (c1,p1) (c2,p0) ... -- every
+  // second half one pass (~2.2 MB) after the first, and the narrow last chunk
+  // right behind the passes of the chunk it shares its line with.  The packed
+  // operand keeps its layout ([chunk][parity][taps]); the weight stages' scalar
+  // offset jumps at pass boundaries instead of running linearly.
+  int chunk_inner;
 };
 
 constexpr int kSwpRing = 3;       // weight ring depth
@@ -189,6 +201,7 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   const int chunk0 = zsplit * a.nchunks;
   const int gnp = a.gn * a.gp;
   const int full_passes = (a.nchunks - (NRW ? 1 : 0)) * R;
+  const int nfull = a.nchunks - (NRW ? 1 : 0);  // full channel chunks of this walk
   // logical 16-byte chunk this lane fetches: pieces start at multiples of 16
   // rows, so row bit 2 is lane bit 4 for every piece
   const int aq = (lane & 3) ^ (((lane >> 4) & 1) << 1);
@@ -405,7 +418,22 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
   // window piece of pass p of the running tile (p > 0 while its predecessor runs)
   auto issue_a_cur = [&](int p, int k, uint32_t w) {
     const bool np = NRW && p >= full_passes;
-    issue_a_piece(rx, (wbuf ^ 1), R == 2 ? (p >> 1) : p, R == 2 ? (p & 1) : 0, np, k, w);
+    int cc = p, par = 0;
+    if constexpr (R == 2) {
+      if (pa.chunk_inner) {
+        if (p < 4 * (nfull >> 1)) {  // a whole pair of chunks: 4 passes
+          cc = 2 * (p >> 2) + (p & 1);
+          par = (p >> 1) & 1;
+        } else {                     // the odd last full chunk: its two parities
+          cc = nfull - 1;
+          par = p - 4 * (nfull >> 1);
+        }
+      } else {
+        cc = p >> 1;
+        par = p & 1;
+      }
+    }
+    issue_a_piece(rx, (wbuf ^ 1), cc, par, np, k, w);
   };
   // piece slot K (compile-time) of pass p; returns 1 if this wave owns it
   auto issue_a_slot = [&](int p, auto k_tag) {
@@ -643,6 +671,17 @@ __device__ __forceinline__ void swconv_swp_body(const SwpArgs& pa) {
         // the stream's stage s + 3 is the next tile's first
         if (last && stream_next)
           bstage = first_stage_of(to_sgpr(n_wtile));
+      }
+      if constexpr (R == 2 && !NARROW && s == NSTG - 3) {
+        // this issue is the next pass's first stage: with the chunk innermost the
+        // operand ([chunk][parity][taps]) is not walked linearly
+        if (pa.chunk_inner && p < 4 * (nfull >> 1)) {
+          // (chunk, parity) sits at (2 chunk + parity) PB; inside a pair the walk
+          // is +0, +2, +1, +3 PB: jumps +1, -2, +1, 0 behind the linear advance
+          constexpr int PB = NST * KS * 32 * 2;  // bytes of one (chunk, parity)
+          const int r = p & 3;
+          bstage += r == 3 ? 0 : (r == 1 ? -2 * PB : PB);
+        }
       }
       if (!ends || s + 3 < NSTG) issue_b(s % kSwpRing);
       mfma_step(af1, bf1);
@@ -1417,6 +1456,13 @@ int swconv_swp_launch(const ConvArgs& a, int stride, int wm, int wn, int mt,
   pa.total_stages = (a.nchunks - narrow) * stride * pa.nst + narrow * 4;
   pa.npad_rows = (a.N + 127) / 128 * 128;
   pa.inv_WRs = 1.0f / (float)pa.WRs;
+  {
+    static const bool off = [] {  // CALCIUMGAN_SWP_CHUNK_INNER=0: the old order (A/B)
+      const char* e = getenv("CALCIUMGAN_SWP_CHUNK_INNER");
+      return e && e[0] == '0';
+    }();
+    pa.chunk_inner = (stride == 2 && !off) ? 1 : 0;
+  }
   // (window buffers at the tile's compile-time stride: KPW pieces per wave)
   const int tm = wm * mt * 16;
   const int npa_max = tm / 16 + 6;

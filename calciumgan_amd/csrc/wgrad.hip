@@ -1478,6 +1478,7 @@ extern "C" long long cg_wgrad_partials_elems(const cg_wgrad_desc* d) {
   if (!d) return -1;
   cg_wgrad_desc c = *d;
   c.partials = nullptr;
+  c.store = 0;  // (a size query: `store` without a workspace is its own error)
   WgradPlan p;
   const int rc = plan_wgrad(&c, p);
   return rc ? -1 : p.part_elems;

@@ -56,6 +56,12 @@ class _Model(object):
     self.net.repack()
 
   def count_params(self):
+    """Keras Model.count_params(): every weight, the non-trainable ones
+    (BatchNormalization's moving statistics) included; utils.count_trainable_params
+    / count_trainable_params() give the trainable figure."""
+    return int(sum(int(np.prod(v.shape)) for v in self.net.params.views))
+
+  def count_trainable_params(self):
     return self.net.params.count
 
   def summary(self):
@@ -63,14 +69,20 @@ class _Model(object):
     for i, v in enumerate(self.net.params.views):
       print('  [{:02d}] {:<22} {}'.format(i, str(tuple(v.shape)),
                                           int(np.prod(v.shape))))
-    print('Total params: {:,}'.format(self.count_params()))
+    total, trainable = self.count_params(), self.count_trainable_params()
+    print('Total params: {:,}'.format(total))
+    print('Trainable params: {:,}'.format(trainable))
+    print('Non-trainable params: {:,}'.format(total - trainable))
 
 
 class Generator(_Model):
   name = 'generator'
 
-  def __call__(self, noise, training=True):
-    """noise (B, noise_dim) -> (B, L, C) float32 (sigmoid when normalize)."""
+  def __call__(self, noise, training=False):
+    """noise (B, noise_dim) -> (B, L, C) float32 (sigmoid when normalize).
+    training defaults to False as for a Keras model called without it: with
+    --batch_norm the moving statistics normalise and are left alone (the
+    algorithms pass training explicitly; calciumgan.py:22-103)."""
     _lib_use(self.net.precision)
     noise = torch.as_tensor(noise, dtype=torch.float32).to(
         self.net.device).contiguous()

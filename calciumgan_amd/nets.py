@@ -121,10 +121,12 @@ _REDUCE_WS = {}
 
 def reduce_ws(device):
   """The shared workspace of the ordered reductions (cg_reduce_ws_elems floats,
-  one per device and precision: launches are stream-ordered), or None."""
+  one per device, precision and STREAM: what makes sharing it safe is that the
+  launches that use it are ordered on one stream -- ADVICE r4), or None."""
   if not DETERMINISTIC:
     return None
-  key = (str(device), _lib.active())
+  key = (str(device), _lib.active(),
+         torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
   ws = _REDUCE_WS.get(key)
   if ws is None:
     n = _lib.load().cg_reduce_ws_elems()
@@ -433,6 +435,8 @@ def _autotune_tile(d):
     # fused LayerNorm), if the library admits it for this launch; else the
     # static tile-kernel choice stays
     best = _static_swp_choice(d)
+    if best is not None:
+      _TILE_CACHE[key] = best  # (every rank holds the table it launches)
     if multi:
       parallel.broadcast_object(best)
     return _apply_tile_choice(d, best)

@@ -749,7 +749,7 @@ def _wgrad_cases():
   out = []
   for case in WGRAD_CASES:
     nB, L, Ci, Co, k, seg, use_shift = case
-    for partials in (False, True):
+    for partials in (False, 'add', 'store'):
       for classic in (0, 1):
         if partials:
           d = _wgrad_test_desc(_PH, _PH, _PH, nB, L, Ci, Co, k, seg_size=seg)
@@ -763,8 +763,12 @@ def _wgrad_cases():
 @pytest.mark.parametrize('nB,L,Ci,Co,k,seg,use_shift,partials,classic',
                          _wgrad_cases())
 def test_conv_wgrad_bitexact(nB, L, Ci, Co, k, seg, use_shift, partials, classic):
-  """partials = True: the K' splits store partial sums that a second launch
-  adds into dw (which must ACCUMULATE: dw starts at 1); False: f32 atomics.
+  """partials: the K' splits store partial sums that a second launch adds into
+  dw -- 'add': dw ACCUMULATES (it starts at 1), 'store': dw and dbias are stored
+  (cg_wgrad_desc.store, the ordered mode's form); False: f32 atomics.  (Until
+  round 5 the partial-sum cases were skipped by mistake: the size query answered
+  an error for descriptors with `store` set, and the test took that for "one K'
+  split" -- found when the skips were turned into collection-time checks.)
   classic = 1: register-staged tiles instead of the LDS-DMA ring (the 24-tap
   cases whose samples span whole tiles take the ring by default)."""
   rng = np.random.RandomState(7)
@@ -794,9 +798,13 @@ def test_conv_wgrad_bitexact(nB, L, Ci, Co, k, seg, use_shift, partials, classic
     assert need > 0
     ws = torch.full((need,), float('nan'), device=H.DEV)
     d.partials, d.partials_elems = ws.data_ptr(), need
+    d.store = int(partials == 'store')
+    if d.store:
+      dbias.fill_(5.0)
   H.run_wgrad(d)
   H.sync()
-  np.testing.assert_array_equal(dw.cpu().numpy(), W.grad.numpy() + 1.0)
+  np.testing.assert_array_equal(dw.cpu().numpy(),
+                                W.grad.numpy() + (0.0 if partials == 'store' else 1.0))
   np.testing.assert_array_equal(dbias.cpu().numpy(),
                                 dy[:nb_bias].sum((0, 1)).numpy())
 
@@ -832,7 +840,11 @@ def test_dense_wgrad_bitexact(B, L, Ci, Co):
   np.testing.assert_array_equal(dw.cpu().numpy(), ref.numpy())
 
 
-@pytest.mark.parametrize('rows,C', [(300, 102), (64, 320), (17, 40)])
+@pytest.mark.parametrize('rows,C', [(300, 102), (64, 320), (17, 40),
+                                    # pitches whose 8-channel groups are not a power
+                                    # of two: the 8-lanes-per-row forward (round 5)
+                                    (1000, 192), (33, 400), (129, 224), (70, 96),
+                                    (4099, 320)])
 def test_layernorm_lrelu_fwd_bwd(rows, C):
   rng = np.random.RandomState(10)
   cp = geo.pitch(C)
@@ -1268,6 +1280,40 @@ def test_wgrad_batched_equals_individual_launches(wgrad_form):
   assert torch.equal(dws[0], dws[1])
   assert torch.equal(outs_b[0][0], outs_a[0][0])
   assert torch.equal(outs_b[1][0], outs_a[1][0])
+
+
+@pytest.mark.parametrize('rows,C,centre,spread', [(3000, 102, 50.0, 1.0),
+                                                  (70000, 64, -200.0, 2.0),
+                                                  (517, 320, 50.0, 50.0)])
+def test_batchnorm_statistics_of_off_centre_channels(rows, C, centre, spread):
+  """cg_bn_stats on channels whose mean is large against their spread:
+  Keras' BatchNormalization takes tf.nn.moments, mean((y - mean)^2); a one-pass
+  E[y^2] - E[y]^2 in f32 cancels there (|mean| / std = 50 .. 100: the round-4
+  kernel was 1e-2 off in the variance and clamped negative results to 0).  The
+  kernel sums around each block's own first row and combines the blocks' (count,
+  mean, M2); checked against float64 moments of the same bf16-stored values."""
+  rng = np.random.RandomState(14)
+  cp = geo.pitch(C)
+  offs = centre * (1.0 + 0.1 * rng.rand(C)).astype(np.float32)
+  y = torch.tensor(rng.randn(1, rows, C).astype(np.float32) * spread + offs)
+  yd = H.to_pitch(y, cp)
+  yq = yd.float().cpu()[0, :, :C].double()
+  mean_r = yq.mean(0)
+  var_r = ((yq - mean_r)**2).mean(0)
+  mean = torch.zeros(C, device=H.DEV)
+  var = torch.zeros(C, device=H.DEV)
+  mm = torch.zeros(C, device=H.DEV)
+  mv = torch.ones(C, device=H.DEV)
+  first = None
+  for _ in range(2):
+    _lib.call('cg_bn_stats', H.p(yd), rows, C, cp, H.p(mean), H.p(var), H.p(mm),
+              H.p(mv), 0.99, H.p(H.reduce_ws()), H.stream())
+    H.sync()
+    if first is None:
+      first = (mean.clone(), var.clone())
+  assert torch.equal(first[0], mean) and torch.equal(first[1], var)  # ordered sums
+  np.testing.assert_allclose(mean.cpu().numpy(), mean_r.numpy(), rtol=2e-6)
+  np.testing.assert_allclose(var.cpu().numpy(), var_r.numpy(), rtol=1e-4)
 
 
 @pytest.mark.parametrize('rows,C,act', [(3000, 102, 1), (517, 320, 0), (64, 16, 1)])

@@ -222,6 +222,30 @@ def test_trained_models_reach_the_oracles_statistics(capsys, fixed_tiles):
     print('    oracle seed vs oracle seed: rate %s %%, covariance %s %%' % (
         ['%.1f' % (100 * v[0]) for v in pair_pop],
         ['%.1f' % (100 * v[1]) for v in pair_pop]))
+    # the clause as a MEASUREMENT.  Seed-ensemble means with
+    # their standard errors, and the resolution this design can reach: the
+    # difference of two n-seed ensemble means has standard error sqrt(2 / n) x the
+    # seed-to-seed standard deviation, so "within 2 %" is decidable (2 sigma) only
+    # with n >= 2 (2 s / 2 %)^2 seeds when one seed scatters by s.
+    n = len(rows)
+    print('  seed-ensemble means (n = %d seeds; +- = standard error of the mean):' % n)
+    for k, name, unit in ((0, 'population firing rate', 'Hz'),
+                          (1, 'mean covariance', '')):
+      h = np.array([r['pop_hip'][k] for r in rows], np.float64)
+      o = np.array([r['pop_ora'][k] for r in rows], np.float64)
+      se = lambda x: x.std(ddof=1) / np.sqrt(len(x))
+      diff = (h.mean() - o.mean()) / o.mean()
+      se_diff = np.sqrt(se(h)**2 + se(o)**2) / o.mean()
+      s_seed = 0.5 * (h.std(ddof=1) / h.mean() + o.std(ddof=1) / o.mean())
+      n_need = int(np.ceil(2.0 * (2.0 * s_seed / 0.02)**2))
+      print('    %-24s hip %.5f +- %.5f %s   oracle %.5f +- %.5f %s   truth %.5f' % (
+          name, h.mean(), se(h), unit, o.mean(), se(o), unit, truth_pop[k]))
+      print('      hip - oracle = %+.1f %% +- %.1f %% (1 sigma): %s; one seed scatters '
+            'by %.1f %% -> this design resolves +- %.1f %% (2 sigma); 2 %% would need '
+            '>= %d seeds per side' % (
+                100 * diff, 100 * se_diff,
+                'indistinguishable' if abs(diff) <= 2 * se_diff else 'distinguishable',
+                100 * s_seed, 200 * se_diff, n_need))
     v_hip = max(pct(r['hip_ora']) for r in rows)
     print('  2 %% bar of north_star: hip vs oracle %.1f %% -> %s; the reference '
           "algorithm against itself under another seed %.1f %% -> %s" % (

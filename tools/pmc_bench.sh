@@ -13,7 +13,7 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LD
 python3 - <<'PY'
 import csv, glob, collections, json
 fam_of = lambda n: ('swconv_swp' if 'swconv_swp_kernel' in n else 'swconv' if 'swconv_kernel' in n else
-                    'wgrad' if ('wgrad_multi' in n or 'wgrad_kernel' in n) else None)
+                    'wgrad' if ('wgrad_multi' in n or 'wgrad_kernel' in n or 'wgrad_flex_kernel' in n) else None)
 res = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 dur = collections.defaultdict(lambda: [0, 0.0])
 for d in ('pmc_sq_a', 'pmc_sq_b'):

@@ -22,8 +22,8 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     for r in csv.DictReader(open(fs[-1])):
         n = r['Kernel_Name']
         fam = ('swconv' if ('swconv_kernel' in n or 'swconv_swp_kernel' in n) else
-               'wgrad_reduce' if 'wgrad_reduce' in n else
-               'wgrad_batched' if 'wgrad_multi' in n else
+               'wgrad_reduce' if ('wgrad_reduce' in n or 'wgrad_flex_reduce' in n) else
+               'wgrad_batched' if ('wgrad_multi' in n or 'wgrad_flex_kernel' in n) else
                'wgrad_single' if ('wgrad_kernel' in n and 'dense1' not in n) else
                # the HBM-bound kernels, one family per kernel
                (__import__('re').search(r'(\w+_kernel)', n).group(1) if '_kernel' in n and 'at::' not in n and 'rocclr' not in n else None))
