@@ -223,9 +223,10 @@ class WGAN_GP(GAN):
     return [fake[i * B:(i + 1) * B] for i in range(n)]
 
   def _critic_compute(self, real, r=None, slot=0, real_cached=False,
-                      fake=None):
+                      fake=None, alpha=None):
     """wgan_gp.py:64-80 up to (not including) the optimizer update: leaves the
-    critic gradients in discriminator.net.params.grad."""
+    critic gradients in discriminator.net.params.grad.  alpha: this update's
+    interpolation draws when the caller drew all updates' at once."""
     B = real.shape[0]
     st = self._get_state(B)
     net_d = self.discriminator.net
@@ -233,10 +234,10 @@ class WGAN_GP(GAN):
     if fake is None:
       fake = self._critic_generate(real, r)
     if r is None:
-      alpha = self._streams.alpha(B)
+      alpha = self._streams.alpha(B) if alpha is None else alpha
       shifts = self._streams.shifts(3)
     elif 'shifts_dev' in r:  # graph replay: draws staged in device memory
-      alpha = self._streams.alpha(B)
+      alpha = self._streams.alpha(B) if alpha is None else alpha
       shifts = r['shifts_dev']
     else:
       alpha = self._to_device(r['alpha'])
@@ -367,7 +368,8 @@ class WGAN_GP(GAN):
         # the bf16 copy of `real` in X0[0:B] survives a critic step (only the
         # x^ segment is overwritten): converted once per train()
         self._critic_compute(real, rc(i), slot=i, real_cached=i > 0,
-                             fake=None if own_g else box.pop(i))
+                             fake=None if own_g else box.pop(i),
+                             alpha=box.pop(('alpha', i), None))
       return run
 
     def gen_seg():
@@ -410,6 +412,13 @@ class WGAN_GP(GAN):
           for i, f in enumerate(self._critic_generate_all(
               real, [rc(i) for i in range(n)])):
             box[i] = f
+          if rand is None or 'shifts_dev' in rand['critic'][0]:
+            # ... and ONE draw for the interpolation factors of all updates (they
+            # are i.i.d. U[0, 1): four RNG launches fewer per step)
+            B = real.shape[0]
+            a = self._streams.alpha(n * B)
+            for i in range(n):
+              box[('alpha', i)] = a[i * B:(i + 1) * B]
         fns = ([generate_all] + [critic_seg(i, False) for i in range(n)] +
                [generate('g', rg), gen_seg, metrics_seg, last_seg])
 
