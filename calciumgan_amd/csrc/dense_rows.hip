@@ -128,6 +128,157 @@ __global__ __launch_bounds__(kDrThreads, 2) void dense_rows_kernel(
 
 
 // ---------------------------------------------------------------------------
+// The same Dense + sigmoid for the fake batches of ALL critic updates of a step,
+// with the interpolation and the packing of the critic's input fused into its
+// epilogue (round 5).  On one rank the generator runs once per step over n x B
+// samples (WGAN_GP._critic_generate_all); the f32 fake batch it used to write
+// (545 MB at cfg2) was read back by n cg_interp_pack launches that formed
+//     X0_k = [ real | fake_k | x^_k ],  x^ = a real + (1 - a) fake   (wgan_gp.py:38-41)
+// in bf16.  Here a wave takes a 16-row block of the (sample, time) grid, loads its
+// rows of `real` ONCE, and for k = 0 .. n - 1 computes update k's 16 output rows
+// and stores the three bf16 segments of X0_k directly: no f32 fake batch in HBM,
+// `real` read once instead of n times.  Same arithmetic, same order: the bytes of
+// X0_k equal those of cg_dense_rows + cg_interp_pack (tests/test_hip_kernels.py).
+// ---------------------------------------------------------------------------
+constexpr int kMaxInterp = 8;
+struct DenseInterpArgs {
+  const uint16_t* x;    // bf16 [n * B * L][Cx]: the generator's last hidden layer
+  const uint16_t* w;
+  const float* bias;
+  const float* real;    // f32 [B * L][Cr]
+  const float* alpha;   // f32 [n * B]
+  uint16_t* x0[kMaxInterp];  // per update: bf16 [3 B][L][Cp]
+  int n, B, L, Cx, N, Cr, Cp, epilogue;
+};
+
+template <int KSTEPS>
+__global__ __launch_bounds__(kDrThreads, 2) void dense_rows_interp_kernel(
+    DenseInterpArgs a) {
+  __shared__ float tile[4][16 * kDrPitch];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int r16 = lane & 15;
+  const int g = lane >> 4;
+  act8 wf[KSTEPS][8];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+      wf[ks][nt] = *reinterpret_cast<const act8*>(
+          a.w + (((long long)(nt * 16 + r16) * KSTEPS + ks) * 16 + g) * 8);
+  float* tl = tile[wave];
+  const int tcol = (lane & 31) * 4;
+  const int trow = lane >> 5;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  f32x4 keep = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (tcol + e < a.N) {
+      keep[e] = 1.f;
+      if (a.bias) bv[e] = a.bias[tcol + e];
+    }
+  const bool sig = a.epilogue == CG_EPI_SIGMOID;
+  const long long R = (long long)a.B * a.L;  // rows of one update (L % 16 == 0)
+  const long long nblk = R / 16;
+  const long long nitem = nblk * a.n;        // (block, update) pairs, update fastest
+  const long long stride = (long long)gridDim.x * 4;
+  const long long seg = R * a.Cp;            // elements of one segment of X0
+  auto load_a = [&](long long blk, int k, bool ok, act8 (&dst)[KSTEPS]) {
+    const long long row = (long long)k * R + blk * 16 + r16;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      act8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok) v = *reinterpret_cast<const act8*>(a.x + row * a.Cx + ks * 32 + g * 8);
+      dst[ks] = v;
+    }
+  };
+  auto store4 = [&](uint16_t* p, const f32x4& v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2act(v[0], v[1]), pack2act(v[2], v[3]));
+  };
+  auto compute = [&](long long blk, int k, const act8 (&af)[KSTEPS]) {
+    f32x4 acc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+        acc[nt] = cg_mfma_16x16x32(af[ks], wf[ks][nt], acc[nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        tl[(4 * g + r) * kDrPitch + nt * 16 + r16] = acc[nt][r];
+    // this lane's share of the block's `real` rows, into the registers the
+    // accumulators just left (HBM once per block: updates 1 .. n - 1 of the block
+    // follow at once and find the lines in L2; holding them across the MFMAs of
+    // all n updates spilled 12 registers)
+    f32x4 rr[8];
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const long long m = blk * 16 + pass * 2 + trow;
+      const float* p = a.real + m * a.Cr + tcol;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (tcol + e < a.N) v[e] = p[e];
+      rr[pass] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int b = (int)((blk * 16) / a.L);  // the block's sample
+    const float al = a.alpha[k * a.B + b];
+    uint16_t* x0 = a.x0[k];
+#pragma unroll 2
+    for (int pass = 0; pass < 8; ++pass) {
+      const int row = pass * 2 + trow;
+      const long long m = blk * 16 + row;
+      f32x4 f = *reinterpret_cast<const f32x4*>(tl + row * kDrPitch + tcol);
+      f32x4 xh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = f[e] + bv[e];
+        const float sg = 1.f / (1.f + __expf(-t));
+        f[e] = (sig ? sg : t) * keep[e];
+        xh[e] = al * rr[pass][e] + (1.f - al) * f[e];
+      }
+      if (tcol < a.Cp) {
+        uint16_t* q = x0 + m * a.Cp + tcol;
+        store4(q, rr[pass]);
+        store4(q + seg, f);
+        store4(q + 2 * seg, xh);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // items (block, update) of this wave: blocks blk0, blk0 + stride, ..., every
+  // update of a block in turn; two statically named fragment sets
+  long long blk = (long long)blockIdx.x * 4 + wave;
+  int k = 0;
+  auto advance = [&](long long& bb, int& kk) {
+    if (++kk == a.n) { kk = 0; bb += stride; }
+  };
+  act8 af0[KSTEPS], af1[KSTEPS];
+  load_a(blk, k, blk < nblk, af0);
+  (void)nitem;
+  while (blk < nblk) {
+    long long nb = blk; int nk = k;
+    advance(nb, nk);
+    load_a(nb, nk, nb < nblk, af1);
+    compute(blk, k, af0);
+    blk = nb; k = nk;
+    if (blk >= nblk) break;
+    advance(nb, nk);
+    load_a(nb, nk, nb < nblk, af0);
+    compute(blk, k, af1);
+    blk = nb; k = nk;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Wide form: K and / or N beyond 128 (BASELINE configs[4]: 512 -> 512 per
 // timestep over 2 M rows -- as a cg_swconv launch it ran at 0.2 PFLOP/s, 19 % of
 // that configuration's step).  W no longer fits a wave's registers, so a
@@ -550,6 +701,43 @@ extern "C" int cg_dense_rows(const void* x, const void* w, const float* bias,
     case 2: hipLaunchKernelGGL(dense_rows_kernel<2>, grid, block, 0, s, a); break;
     case 3: hipLaunchKernelGGL(dense_rows_kernel<3>, grid, block, 0, s, a); break;
     default: hipLaunchKernelGGL(dense_rows_kernel<4>, grid, block, 0, s, a); break;
+  }
+  CG_LAUNCH_CHECK();
+}
+
+// cg_dense_rows for the fake batches of all n critic updates of a step, fused
+// with cg_interp_pack: x0[k] (bf16 [3 B][L][Cp]) receives [real | fake_k | x^_k].
+extern "C" int cg_dense_rows_interp(const void* x, const void* w, const float* bias,
+                                    const float* real, const float* alpha,
+                                    void* const* x0, int n, int B, int L, int Cx,
+                                    int N, int Cr, int Cp, int epilogue,
+                                    void* stream) {
+  if (!x || !w || !real || !alpha || !x0 || n < 1 || n > kMaxInterp || B < 1 || L < 16 ||
+      L % 16)
+    return CG_EINVAL;
+  if (epilogue != CG_EPI_NONE && epilogue != CG_EPI_SIGMOID) return CG_EINVAL;
+  if (Cx % 32 || Cx < 32 || Cx > 128 || N < 1 || N > 128 || Cp != 128 || Cr < N)
+    return CG_EINVAL;
+  DenseInterpArgs a;
+  a.x = reinterpret_cast<const uint16_t*>(x);
+  a.w = reinterpret_cast<const uint16_t*>(w);
+  a.bias = bias; a.real = real; a.alpha = alpha;
+  for (int k = 0; k < kMaxInterp; ++k)
+    a.x0[k] = k < n ? reinterpret_cast<uint16_t*>(x0[k]) : nullptr;
+  for (int k = 0; k < n; ++k)
+    if (!a.x0[k]) return CG_EINVAL;
+  a.n = n; a.B = B; a.L = L; a.Cx = Cx; a.N = N; a.Cr = Cr; a.Cp = Cp;
+  a.epilogue = epilogue;
+  const long long nblk = (long long)B * L / 16;
+  long long blocks = (nblk + 3) / 4;
+  if (blocks > 512) blocks = 512;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)blocks), block(kDrThreads);
+  switch (Cx / 32) {
+    case 1: hipLaunchKernelGGL(dense_rows_interp_kernel<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(dense_rows_interp_kernel<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(dense_rows_interp_kernel<3>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(dense_rows_interp_kernel<4>, grid, block, 0, s, a); break;
   }
   CG_LAUNCH_CHECK();
 }

@@ -47,6 +47,11 @@ _DP_OVERLAP = os.environ.get('CALCIUMGAN_DP_OVERLAP', '1') != '0'
 # the penalty norm's finishing sum, gp / coef / critic loss and v's per-sample
 # scale as ONE launch (cg_gp_loss_scale) instead of three (A/B: =0)
 _FUSE_GP = os.environ.get('CALCIUMGAN_FUSE_GP', '1') != '0'
+# single rank, batched generator pass: the output Dense of that pass writes the
+# critic's input buffers of ALL updates itself -- interpolation and packing in its
+# epilogue (cg_dense_rows_interp), one input buffer per update -- instead of an
+# f32 fake batch that n_critic cg_interp_pack launches read back (A/B: =0)
+_FUSE_INTERP = os.environ.get('CALCIUMGAN_FUSE_INTERP', '1') != '0'
 _METRIC_KEYS = ('signals_metrics/min', 'signals_metrics/max',
                 'signals_metrics/mean', 'signals_metrics/std')
 # pinned staging slots for the host-drawn inputs of a graph replay: the host may
@@ -109,6 +114,33 @@ class WGAN_GP(GAN):
       self._state[B] = st
     return st
 
+  def _critic_plan(self, st, k):
+    """The critic plan whose layer-1 launches read input buffer k of the step
+    (_DisWorkspace.x0): plan 0 is st['critic']; the others are built on first use
+    with the same seeds and tangent chain."""
+    if k == 0:
+      return st['critic']
+    plans = st.setdefault('critic_alt', {})
+    pl = plans.get(k)
+    if pl is None:
+      B = st['coef_gp'].shape[0]
+      pl = plans[k] = st['dws'].plan(3 * B, B, 2 * B, x0_index=k)
+      pl.coef.copy_(st['critic'].coef)
+      pl.bias_coef.copy_(st['critic'].bias_coef)
+      pl.build_jvp(2, st['coef_gp'])
+      if st['critic'].norm_deferred:
+        pl.defer_norm()
+    return pl
+
+  def _can_fuse_interp(self, B, n):
+    """cg_dense_rows_interp applies: bf16 build (no loss scale on the seeds), the
+    register form of the output Dense, n <= 8 updates."""
+    if not _FUSE_INTERP or self.dis_optimizer.loss_scale is not None:
+      return False
+    gws = self.generator.net.workspace(n * B, forward_only=True)
+    lay = self.discriminator.net.layers[0]
+    return gws.can_interp(n) and lay.cinp == self.generator.net.Cp
+
   def batch_buffer(self, B):
     """The device buffer train() reads a batch of B samples from when it replays
     its hipGraph: (B,) + signal_shape, f32.  A data loader that gathers every
@@ -140,7 +172,8 @@ class WGAN_GP(GAN):
     return -fake_output.mean()
 
   def _critic_forward(self, st, real, z, alpha, shifts, slot,
-                      real_cached=False, fake=None, training=True, scale=None):
+                      real_cached=False, fake=None, training=True, scale=None,
+                      plan=None, packed=False):
     """Steps 1-5 of the critic schedule; leaves g in st['critic'].gin.  `fake`
     is G(z) when the generator forward already ran (_critic_generate).
     training=False (validate, gan.py:87-90): BatchNormalization layers use their
@@ -148,18 +181,19 @@ class WGAN_GP(GAN):
     net_d = self.discriminator.net
     B = real.shape[0]
     lay = net_d.layers[0]
-    plan = st['critic']
+    plan = st['critic'] if plan is None else plan
     s = nets._stream()
     # (host-drawn shifts of an eager step are a pageable temporary: a
     # non-blocking copy could read it after it is gone once the host runs ahead
     # of the GPU; the graph path hands a device view)
     plan.shifts.copy_(shifts, non_blocking=shifts.is_cuda)
     self._scale_seeds(st, 'critic', self.dis_optimizer)
-    if fake is None:
-      fake = st['gws'].forward(z, keep=False, training=training)
-    _lib.call('cg_interp_pack', nets._p(real), nets._p(fake), nets._p(alpha),
-              nets._p(st['dws'].act[0]), B, lay.lin, lay.cin, lay.cin,
-              self.generator.net.Cf, lay.cinp, 0 if real_cached else 1, s)
+    if not packed:  # (packed: plan.x0 already holds [real | fake | x^])
+      if fake is None:
+        fake = st['gws'].forward(z, keep=False, training=training)
+      _lib.call('cg_interp_pack', nets._p(real), nets._p(fake), nets._p(alpha),
+                nets._p(plan.x0), B, lay.lin, lay.cin, lay.cin,
+                self.generator.net.Cf, lay.cinp, 0 if real_cached else 1, s)
     plan.forward(seed_backward=True)
     plan.backward_chain(seeded=True)
     n = lay.lin * lay.cinp
@@ -207,23 +241,26 @@ class WGAN_GP(GAN):
       z = self._to_device(r['z'])
     return st['gws'].forward(z, keep=keep)
 
-  def _critic_generate_all(self, real, rs):
-    """G(z) of ALL critic updates of one train() as one forward-only pass
-    over len(rs) * B samples: the generator does not change between them
+  def _critic_generate_all(self, real, z, n, alphas=None):
+    """G(z) of ALL n critic updates of one train() as one forward-only pass
+    over n * B samples: the generator does not change between them
     (wgan_gp.py:84-90 updates only the critic), and the small early layers run
-    far better at 5 B.  Returns one (B, L, Cf) view per update."""
+    far better at 5 B.  Returns one (B, L, Cf) view per update -- or, with
+    alphas (f32, n * B: the interpolation factors of all updates), a list of
+    None: the output Dense then writes [real | fake_k | x^_k] into update k's
+    input buffer itself (cg_dense_rows_interp; no f32 fake batch)."""
     B = real.shape[0]
-    n = len(rs)
-    if rs[0] is None or 'shifts_dev' in rs[0]:
-      z = self.get_noise(n * B)
-    else:
-      z = torch.cat([self._to_device(r['z']) for r in rs], 0)
     ws = self.generator.net.workspace(n * B, forward_only=True)
+    if alphas is not None:
+      st = self._get_state(B)
+      ws.forward(z, keep=False,
+                 interp=(real, alphas, [st['dws'].x0(k) for k in range(n)]))
+      return [None] * n
     fake = ws.forward(z, keep=False)
     return [fake[i * B:(i + 1) * B] for i in range(n)]
 
   def _critic_compute(self, real, r=None, slot=0, real_cached=False,
-                      fake=None, alpha=None):
+                      fake=None, alpha=None, x0_index=None):
     """wgan_gp.py:64-80 up to (not including) the optimizer update: leaves the
     critic gradients in discriminator.net.params.grad.  alpha: this update's
     interpolation draws when the caller drew all updates' at once."""
@@ -231,7 +268,8 @@ class WGAN_GP(GAN):
     st = self._get_state(B)
     net_d = self.discriminator.net
     lay = net_d.layers[0]
-    if fake is None:
+    packed = x0_index is not None  # (the step's generator pass packed X0_k)
+    if fake is None and not packed:
       fake = self._critic_generate(real, r)
     if r is None:
       alpha = self._streams.alpha(B) if alpha is None else alpha
@@ -246,7 +284,7 @@ class WGAN_GP(GAN):
           torch.as_tensor(r['shifts_fake'], dtype=torch.int32),
           torch.as_tensor(r['shifts_inter'], dtype=torch.int32)
       ], dim=1)
-    plan = st['critic']
+    plan = self._critic_plan(st, x0_index or 0)
     n = lay.lin * lay.cinp
     if plan.jvp_folds:
       # g already sits over the x^ segment of X0; v = lambda * dgp/dg = coef_b * g
@@ -258,9 +296,9 @@ class WGAN_GP(GAN):
     else:
       # v = lambda * dgp/dg, written over the x^ segment of X0 (in place when g
       # already sits there)
-      scale = (plan.gin, st['dws'].act[0][2 * B:], n)
+      scale = (plan.gin, plan.x0[2 * B:], n)
     self._critic_forward(st, real, None, alpha, shifts, slot, real_cached,
-                         fake=fake, scale=scale)
+                         fake=fake, scale=scale, plan=plan, packed=packed)
     s = nets._stream()
     if not plan.norm_deferred:  # (else cg_gp_loss_scale has scaled the rows)
       _lib.call('cg_scale_rows', nets._p(scale[0]), nets._p(st['coef_gp']),
@@ -369,7 +407,8 @@ class WGAN_GP(GAN):
         # x^ segment is overwritten): converted once per train()
         self._critic_compute(real, rc(i), slot=i, real_cached=i > 0,
                              fake=None if own_g else box.pop(i),
-                             alpha=box.pop(('alpha', i), None))
+                             alpha=box.pop(('alpha', i), None),
+                             x0_index=i if box.get('packed') else None)
       return run
 
     def gen_seg():
@@ -409,15 +448,24 @@ class WGAN_GP(GAN):
         # ... and no all-reduce for G(z_i) to hide behind: all critic updates'
         # fake batches come from ONE generator pass at the start of the step
         def generate_all():
-          for i, f in enumerate(self._critic_generate_all(
-              real, [rc(i) for i in range(n)])):
-            box[i] = f
-          if rand is None or 'shifts_dev' in rand['critic'][0]:
-            # ... and ONE draw for the interpolation factors of all updates (they
-            # are i.i.d. U[0, 1): four RNG launches fewer per step)
-            B = real.shape[0]
+          B = real.shape[0]
+          rs = [rc(i) for i in range(n)]
+          drawn = rs[0] is None or 'shifts_dev' in rs[0]
+          fuse = self._can_fuse_interp(B, n)
+          # one draw each for the noise and (they are i.i.d. U[0, 1): four RNG
+          # launches fewer per step) the interpolation factors of all updates
+          if drawn:
+            z = self.get_noise(n * B)
             a = self._streams.alpha(n * B)
-            for i in range(n):
+          else:  # injected draws (parity tests)
+            z = torch.cat([self._to_device(r['z']) for r in rs], 0)
+            a = (torch.cat([self._to_device(r['alpha']).reshape(-1) for r in rs])
+                 if fuse else None)
+          fakes = self._critic_generate_all(real, z, n, alphas=a if fuse else None)
+          box['packed'] = fuse
+          for i in range(n):
+            box[i] = fakes[i]
+            if a is not None:
               box[('alpha', i)] = a[i * B:(i + 1) * B]
         fns = ([generate_all] + [critic_seg(i, False) for i in range(n)] +
                [generate('g', rg), gen_seg, metrics_seg, last_seg])

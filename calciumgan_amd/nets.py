@@ -760,26 +760,44 @@ class _DisWorkspace(object):
     self.d_out = z(nB, dt=torch.float32)
     self._plans = {}
 
-  def plan(self, nB, seg_size, input_grad_from, want_norm=True):
+  def x0(self, k):
+    """Input buffer X0 of critic update k of a step: update 0 uses act[0]; the
+    others get their own buffer, so that ONE launch at the start of the step
+    (cg_dense_rows_interp) can leave every update's [real | fake_k | x^_k] in
+    place (WGAN_GP._critic_generate_all).  201 MB each at cfg2."""
+    if k == 0:
+      return self.act[0]
+    alt = self.__dict__.setdefault('_x0_alt', {})
+    if k not in alt:
+      alt[k] = torch.zeros_like(self.act[0])
+    return alt[k]
+
+  def plan(self, nB, seg_size, input_grad_from, want_norm=True, x0_index=0):
     """Descriptors for a run over the first nB samples with shift segments of
     seg_size samples; the layer-1 input gradient is computed for samples
     [input_grad_from, nB) (None = not at all).  want_norm: its per-sample sum of
     squares (the penalty norm) is taken in the same launch -- the generator
-    update's pass does not need it."""
-    key = (nB, seg_size, input_grad_from, bool(want_norm))
+    update's pass does not need it.  x0_index: which of the step's input
+    buffers (x0(k)) the layer-1 launches read."""
+    key = (nB, seg_size, input_grad_from, bool(want_norm), int(x0_index))
     pl = self._plans.get(key)
     if pl is None:
-      pl = _DisPlan(self, nB, seg_size, input_grad_from, want_norm)
+      pl = _DisPlan(self, nB, seg_size, input_grad_from, want_norm,
+                    x0=self.x0(x0_index))
       self._plans[key] = pl
     return pl
 
 
 class _DisPlan(object):
 
-  def __init__(self, ws, nB, seg_size, input_grad_from, want_norm=True):
+  def __init__(self, ws, nB, seg_size, input_grad_from, want_norm=True, x0=None):
     net = ws.net
     dev = net.device
     self.ws, self.nB, self.seg_size = ws, nB, seg_size
+    # the layer-1 input of this plan's launches (ws.act[0] unless the step keeps
+    # one input buffer per critic update: _DisWorkspace.x0)
+    self.x0 = ws.act[0] if x0 is None else x0
+    src = lambda i: self.x0 if i == 0 else ws.act[i]
     self.nseg = (nB + seg_size - 1) // seg_size
     k, pl = net.k, net.pl
     # shifts[l][seg]: PhaseShuffle draw applied after layer l+1 (l = 0..3)
@@ -792,13 +810,13 @@ class _DisPlan(object):
       bias = net.params.views[2 * i + 1]
       op = net.w_fwd[i]
       self.fwd.append(
-          _conv_desc(ws.act[i], op.buf, ws.act[i + 1], nB, lay.lin, lay.cinp, k,
+          _conv_desc(src(i), op.buf, ws.act[i + 1], nB, lay.lin, lay.cinp, k,
                      2, -pl, lay.lout, lay.cout, lay.lout, lay.coutp, op.CK,
                      bias=bias, shifts=sh, seg_size=seg_size,
                      epilogue=_lib.EPI_LRELU, w_parity_major=op.parity_major,
                      w_narrow_last=op.narrow_last, alpha=net.alpha))
       self.wgrad.append(
-          _wgrad_desc(ws.act[i], ws.delta[i + 1], net.params.grad_views[2 * i],
+          _wgrad_desc(src(i), ws.delta[i + 1], net.params.grad_views[2 * i],
                       nB, lay.lin, lay.cinp, lay.lout, lay.coutp, k, 2, -pl,
                       lay.cin, lay.cout, shifts=sh, seg_size=seg_size,
                       dbias=net.params.grad_views[2 * i + 1], slot=i))
@@ -845,7 +863,7 @@ class _DisPlan(object):
       # where the chain's first launch and the layer-1 weight gradient read it
       # (_FOLD_SCALE: no separate pass that scales it by the penalty's coef_b)
       self.gin_in_x0 = _FOLD_SCALE and input_grad_from > 0
-      self.gin = (ws.act[0][input_grad_from:nB] if self.gin_in_x0 else
+      self.gin = (self.x0[input_grad_from:nB] if self.gin_in_x0 else
                   torch.zeros(nG, lay.lin, lay.cinp, dtype=act_dtype(),
                               device=dev))
       # penalty norm fused into this launch's epilogue when a 256-row tile
@@ -894,7 +912,8 @@ class _DisPlan(object):
         op = net.w_fwd[i]
         seg_act = ws.act[i + 1][s0:s0 + n]
         descs.append(
-            _conv_desc(ws.act[i][s0:s0 + n], op.buf, seg_act, n, lay.lin,
+            _conv_desc((self.x0 if i == 0 else ws.act[i])[s0:s0 + n], op.buf,
+                       seg_act, n, lay.lin,
                        lay.cinp, k, 2, -pl, lay.lout, lay.cout, lay.lout,
                        lay.coutp, op.CK, mask_src=seg_act, shifts=sh,
                        seg_size=n, epilogue=_lib.EPI_MASK,
@@ -906,7 +925,7 @@ class _DisPlan(object):
     self.jvp = build(fold)
     # (only the software-pipelined tiles carry the per-sample scale: 24-tap
     # kernels on the GPU; otherwise v is formed by its own pass, as before)
-    self.jvp_folds = bool(fold and ws.act[0].is_cuda and
+    self.jvp_folds = bool(fold and self.x0.is_cuda and
                           lib.cg_swconv_check(ctypes.byref(self.jvp[0])) == 0)
     if fold and not self.jvp_folds:
       self.jvp = build(False)
@@ -1204,8 +1223,18 @@ class _GenWorkspace(object):
     self.b_in_wgrad = _wgrad_desc(self.z, self.dy[0], G[0], B, 1, nd, 1,
                                   w0 * nd, 1, 1, 0, nd, w0 * nd, slot='in')
 
-  def forward(self, z_f32, keep=True, training=True):
+  def can_interp(self, n):
+    """Whether forward(interp=...) exists for this model: the register form of
+    the streaming output Dense, a 128-channel pitch, whole 16-row blocks."""
+    net = self.net
+    return bool(net.streaming_out and net.Cp == 128 and net.L % 16 == 0 and
+                1 <= n <= 8 and self.B % n == 0)
+
+  def forward(self, z_f32, keep=True, training=True, interp=None):
     """z (B, nd) f32 device -> self.fake (B, L, Cf) f32 (first C channels).
+    interp = (real f32 (B / n, L, C), alpha f32 (B), [x0_0 .. x0_{n-1}]): this
+    workspace holds the n fake batches of a step's critic updates; instead of
+    self.fake the critic's input buffers are written (returns None).
     keep=False: forward only (the fake batch of a critic update) -- the fused
     LayerNorm launches then skip the pre-activations and row statistics that
     only backward() reads.  training (BatchNormalization only): batch
@@ -1243,6 +1272,19 @@ class _GenWorkspace(object):
                   _p(V[il + 1]), _p(self.h[i + 1]), _p(self.mean[i + 1]),
                   _p(self.rstd[i + 1]), rows, lay.cout, lay.coutp,
                   LN_EPS, net.alpha, st)
+    if interp is not None:
+      # the fake batches of all critic updates of a step: Dense + sigmoid with the
+      # interpolation and the packing of the critic's inputs in its epilogue --
+      # x0s[k] <- [real | fake_k | x^_k] (cg_dense_rows_interp); no f32 fake batch
+      real, alpha, x0s = interp
+      n = len(x0s)
+      Bu = self.B // n
+      ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in x0s])
+      _lib.call('cg_dense_rows_interp', _p(self.h[-1]), _p(net.w_out.buf),
+                _p(V[net.idx_out + 1]), _p(real), _p(alpha), ptrs, n, Bu, net.L,
+                net.Cp, net.C, net.C, net.Cp,
+                _lib.EPI_SIGMOID if net.normalize else _lib.EPI_NONE, st)
+      return None
     if net.streaming_out:
       # HBM-bound per-timestep Dense (+ sigmoid): the streaming kernel
       _lib.call('cg_dense_rows', _p(self.h[-1]), _p(net.w_out.buf),

@@ -232,6 +232,18 @@ int cg_swconv_check(const cg_conv_desc* d);
 int cg_dense_rows(const void* x, const void* w, const float* bias, float* y,
                   long long rows, int Cx, int N, int Cy, int epilogue,
                   void* stream);
+/* cg_dense_rows (register form: Cx in {32, 64, 96, 128}, N <= 128) for the fake
+ * batches of ALL n critic updates of one train() -- x bf16 [n * B * L][Cx], the
+ * generator's last hidden layer over n * B samples -- fused with cg_interp_pack:
+ * x0[k] (bf16 [3 B][L][Cp], Cp = 128) receives [real | fake_k | x^_k], x^ =
+ * alpha[k * B + b] * real + (1 - alpha) * fake (wgan_gp.py:38-41, interpolation
+ * in f32 on the f32 Dense output as the reference does).  The f32 fake batch
+ * never reaches HBM and `real` (f32 [B][L][Cr]) is read once.  L % 16 == 0,
+ * n <= 8.  The bytes of x0[k] equal those of cg_dense_rows + cg_interp_pack. */
+int cg_dense_rows_interp(const void* x, const void* w, const float* bias,
+                         const float* real, const float* alpha, void* const* x0,
+                         int n, int B, int L, int Cx, int N, int Cr, int Cp,
+                         int epilogue, void* stream);
 /* The same contraction with an activation-typed (bf16 / fp16) output, no bias,
  * no epilogue -- the input gradient of that Dense: dh[r, c] = sum_n dz[r, n] *
  * W[c][n] with `w` the operand packed from W transposed.  Cx in {128, 256, 384,

@@ -66,7 +66,10 @@ def test_atomics_form_is_still_available_and_close():
     'CALCIUMGAN_NARROW_LAST=0', 'CALCIUMGAN_FOLD_SCALE=0',
     'CALCIUMGAN_SWP_TILES=0', 'CALCIUMGAN_WGRAD_XCD=0', 'CALCIUMGAN_SPLIT_K=0',
     'CALCIUMGAN_WGRAD_HALVES=0',
-    'CALCIUMGAN_SPLIT_SEGMENTS=1', 'CALCIUMGAN_SWP_LEAN_EPI=1'])
+    'CALCIUMGAN_SPLIT_SEGMENTS=1', 'CALCIUMGAN_SWP_LEAN_EPI=1',
+    # round 5
+    'CALCIUMGAN_WGRAD_FLEX=0', 'CALCIUMGAN_SWP_CHUNK_INNER=0',
+    'CALCIUMGAN_FUSE_INTERP=0', 'CALCIUMGAN_LN_POW2=1', 'CALCIUMGAN_AUTOTUNE=1'])
 def test_every_documented_switch_is_a_working_configuration(knob):
   """README's switches select older / alternative forms of the same arithmetic.
   Each must still train: the first train() call (five critic updates + one
@@ -95,5 +98,17 @@ def test_fused_penalty_launch_equals_the_three_launches_bit_for_bit():
   shape = (2048, 102, 16, 4)
   a = _run(10, shape)
   b = _run(10, shape, {'CALCIUMGAN_FUSE_GP': '0'})
+  assert a['outputs'] == b['outputs'], (a['last'], b['last'])
+  assert a['weights'] == b['weights']
+
+
+def test_fused_interpolation_equals_the_separate_launches_bit_for_bit():
+  """cg_dense_rows_interp (round 5: the batched generator pass writes every critic
+  update's [real | fake | x^] itself) against cg_dense_rows + n_critic
+  cg_interp_pack launches (CALCIUMGAN_FUSE_INTERP=0): the same arithmetic on the
+  same draws, so ten steps at cfg2's layer shapes end on identical bits."""
+  shape = (2048, 102, 16, 4)
+  a = _run(10, shape)
+  b = _run(10, shape, {'CALCIUMGAN_FUSE_INTERP': '0'})
   assert a['outputs'] == b['outputs'], (a['last'], b['last'])
   assert a['weights'] == b['weights']

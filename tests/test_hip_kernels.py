@@ -653,6 +653,47 @@ def test_dense_rows_streaming(rows, Ci, Co, epi):
     assert float(got[:, Co:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('n,B,L,Ci,C,epi', [(5, 3, 64, 128, 102, 3),
+                                            (2, 70, 16, 64, 102, 0),
+                                            (1, 2, 2048, 128, 128, 3),
+                                            (8, 1, 32, 96, 97, 3)])
+def test_dense_rows_interp_equals_dense_rows_then_interp_pack(n, B, L, Ci, C, epi):
+  """cg_dense_rows_interp -- the generator's output Dense (+ sigmoid,
+  calciumgan.py:96-101) over the fake batches of all n critic updates of a step,
+  with the interpolation and packing of the critic's inputs (wgan_gp.py:38-41) in
+  its epilogue -- against the two launches it replaces, cg_dense_rows (f32 fake
+  batch) + one cg_interp_pack per update: every byte of every update's
+  [real | fake_k | x^_k] equal."""
+  rng = np.random.RandomState(33)
+  cip = geo.pitch(Ci)
+  cp = 128
+  cf = (C + 7) // 8 * 8
+  h = torch.tensor(rng.randn(1, n * B * L, Ci).astype(np.float32))
+  W = torch.tensor(rng.randn(Ci, C).astype(np.float32) * 0.2)
+  b = torch.tensor(rng.randn(C).astype(np.float32) * 0.1)
+  real = torch.tensor(rng.rand(B, L, C).astype(np.float32)).to(H.DEV)
+  alpha = torch.tensor(rng.rand(n * B).astype(np.float32)).to(H.DEV)
+  op = H.pack(W.to(H.DEV), [(0, 1, 0, C, 1)], Ci, C, cip, 32, 1)
+  hd, bd = H.to_pitch(h, cip), b.to(H.DEV)
+  fake = torch.zeros(n * B * L, cf, dtype=torch.float32, device=H.DEV)
+  _lib.call('cg_dense_rows', H.p(hd), H.p(op.buf), H.p(bd), H.p(fake), n * B * L,
+            cip, C, cf, epi, H.stream())
+  ref = []
+  for k in range(n):
+    x0 = torch.full((3 * B, L, cp), 7.0, dtype=BF16, device=H.DEV)
+    _lib.call('cg_interp_pack', H.p(real), H.p(fake[k * B * L:]),
+              H.p(alpha[k * B:]), H.p(x0), B, L, C, C, cf, cp, 1, H.stream())
+    ref.append(x0)
+  got = [torch.full((3 * B, L, cp), 9.0, dtype=BF16, device=H.DEV) for _ in range(n)]
+  ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in got])
+  _lib.call('cg_dense_rows_interp', H.p(hd), H.p(op.buf), H.p(bd), H.p(real),
+            H.p(alpha), ptrs, n, B, L, cip, C, C, cp, epi, H.stream())
+  H.sync()
+  for k in range(n):
+    assert float(ref[k].float().abs().max()) > 0
+    assert torch.equal(ref[k].view(torch.int16), got[k].view(torch.int16)), k
+
+
 @pytest.mark.parametrize('rows,Ci,Co,epi', [(1000, 512, 512, 3), (77, 256, 200, 0),
                                             (4100, 512, 300, 0), (33, 384, 130, 3),
                                             (9000, 128, 102, 0)])
