@@ -752,29 +752,8 @@ struct PackArgs {
 
 // One thread packs one 16-byte group: 8 consecutive channels of one
 // (column n, chunk, tap) -- a single 16-byte store instead of eight 2-byte ones.
-// Thread order: when the source is contiguous in n (s_n == 1: the TF kernel
-// layout read as a forward operand) consecutive threads take consecutive n, so
-// each of the 8 gathers of a wave is one 256-byte run (the 16-byte stores are
-// then scattered, one instruction instead of eight); otherwise consecutive
-// threads follow the destination order and a thread's 8 channels are the
-// contiguous ones (s_c == 1).
-// (32-bit index arithmetic: an operand has < 2^31 groups -- checked on the host --
-// and the 64-bit divisions were most of this kernel's instructions)
-__device__ __forceinline__ void pack_group(const PackArgs& a, unsigned r) {
-  int f, cc, n;
-  if (a.s_n == 1) {
-    const unsigned npad = (unsigned)a.npad;
-    n = (int)(r % npad);
-    const unsigned q = r / npad;
-    f = (int)(q % (unsigned)a.Fp);
-    cc = (int)(q / (unsigned)a.Fp);
-    r = ((unsigned)n * (unsigned)a.nchunks + (unsigned)cc) * (unsigned)a.Fp + (unsigned)f;
-  } else {
-    f = (int)(r % (unsigned)a.Fp);
-    const unsigned q = r / (unsigned)a.Fp;
-    cc = (int)(q % (unsigned)a.nchunks);
-    n = (int)(q / (unsigned)a.nchunks);
-  }
+// the 16-byte group (column n, chunk cc, position f) of a packed operand
+__device__ __forceinline__ uint4 pack_values(const PackArgs& a, int n, int cc, int f) {
   int tap = f / a.c8;
   int q8 = f - tap * a.c8;
   const int half = a.taps >> 1;
@@ -800,30 +779,63 @@ __device__ __forceinline__ void pack_group(const PackArgs& a, unsigned r) {
     for (int e = 0; e < 8; ++e)
       if (c + e < a.C_real) v[e] = src[(long long)(c + e) * a.s_c];
   }
-  *reinterpret_cast<uint4*>(a.dst + (long long)r * 8) =
-      make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]), pack2act(v[4], v[5]),
-                 pack2act(v[6], v[7]));
+  return make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]), pack2act(v[4], v[5]),
+                    pack2act(v[6], v[7]));
+}
+
+// Block `blk` of an operand (256 groups).  Source contiguous in the channels
+// (s_c == 1: the operand's own order is the source's): thread = group, in
+// destination order.  Source contiguous in n (s_n == 1: the TF kernel layout read
+// as a forward operand -- a transpose): the block takes a tile of 32 columns x 8
+// positions; the gathers run along n (128-byte runs), the groups turn around
+// through LDS, and the stores run along the operand's rows (8 x 16 = 128
+// contiguous bytes per column) -- as 64 scattered 16-byte stores per wave they
+// held this kernel at 2.9 TB/s (profiles/r05_hbm_rates.txt).
+// (32-bit index arithmetic: an operand has < 2^31 groups -- checked on the host)
+__device__ __forceinline__ void pack_block(const PackArgs& a, unsigned blk, uint4* lds) {
+  const unsigned tid = threadIdx.x;
+  if (a.s_n == 1) {
+    // tiles: position tile fastest, then column tile, then chunk
+    const unsigned ft = (unsigned)a.Fp >> 3, nt = (unsigned)a.npad >> 5;
+    const unsigned f0 = (blk % ft) * 8;
+    const unsigned q = blk / ft;
+    const unsigned n0 = (q % nt) * 32;
+    const int cc = (int)(q / nt);
+    if (cc >= a.nchunks) return;
+    lds[(tid & 31) * 9 + (tid >> 5)] =
+        pack_values(a, (int)(n0 + (tid & 31)), cc, (int)(f0 + (tid >> 5)));
+    __syncthreads();
+    const unsigned n = n0 + (tid >> 3), f = f0 + (tid & 7);
+    const unsigned r = (n * (unsigned)a.nchunks + (unsigned)cc) * (unsigned)a.Fp + f;
+    *reinterpret_cast<uint4*>(a.dst + (long long)r * 8) = lds[(tid >> 3) * 9 + (tid & 7)];
+    return;
+  }
+  const unsigned r = blk * 256 + tid;
+  if ((long long)r * 8 >= a.total) return;
+  const int f = (int)(r % (unsigned)a.Fp);
+  const unsigned q = r / (unsigned)a.Fp;
+  const int cc = (int)(q % (unsigned)a.nchunks);
+  const int n = (int)(q / (unsigned)a.nchunks);
+  *reinterpret_cast<uint4*>(a.dst + (long long)r * 8) = pack_values(a, n, cc, f);
 }
 
 constexpr int kPackBlock = 256 * 8;  // elements packed by one 256-thread block
 
-__global__ void pack_kernel(PackArgs a) {
-  const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
-  if ((long long)r * 8 >= a.total) return;
-  pack_group(a, r);
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+  __shared__ uint4 lds[32 * 9];
+  pack_block(a, blockIdx.x, lds);
 }
 
 // All operands of one model in ONE launch: `table` holds n PackArgs, block b
 // works on descriptor desc_of_block[b] starting at 16-byte group
 // (b - first_block[desc]) * 256.
-__global__ void pack_batched_kernel(const PackArgs* __restrict__ table,
+__global__ __launch_bounds__(256) void pack_batched_kernel(const PackArgs* __restrict__ table,
                                     const int* __restrict__ desc_of_block,
                                     const int* __restrict__ first_block) {
+  __shared__ uint4 lds[32 * 9];
   const int di = desc_of_block[blockIdx.x];
   const PackArgs a = table[di];
-  const unsigned r = (blockIdx.x - (unsigned)first_block[di]) * blockDim.x + threadIdx.x;
-  if ((long long)r * 8 >= a.total) return;
-  pack_group(a, r);
+  pack_block(a, blockIdx.x - (unsigned)first_block[di], lds);
 }
 
 inline int ilog2(int v) {
