@@ -78,11 +78,21 @@ class WGAN_GP(GAN):
     if st is None:
       dev = self.device
       dws = self.discriminator.net.workspace(3 * B)
+      nc = self.n_critic
+      # host-drawn inputs of a step on the device: [shifts int32 x (12 n + 4) |
+      # Adam step sizes f32 x (n + 1)].  The plans read their PhaseShuffle draws
+      # straight from it (update k: 12 ints at 12 k, the generator update's 4
+      # behind them), so a graph replay needs ONE staged copy and no per-update
+      # copies into the plans
+      stage = torch.zeros(nc * 13 + 5, dtype=torch.int32, device=dev)
       st = dict(
           gws=self.generator.net.workspace(B),
           dws=dws,
-          critic=dws.plan(3 * B, B, 2 * B),
-          gen=dws.plan(B, B, 0, want_norm=False),
+          stage_dev=stage,
+          critic=dws.plan(3 * B, B, 2 * B,
+                          shifts=stage[:12].view(4, 3) if nc > 0 else None),
+          gen=dws.plan(B, B, 0, want_norm=False,
+                       shifts=stage[12 * nc:12 * nc + 4].view(4, 1)),
           norm=torch.zeros(B, dtype=torch.float32, device=dev),
           coef_gp=torch.zeros(B, dtype=torch.float32, device=dev),
           gp=torch.zeros(max(self.n_critic, 1), dtype=torch.float32, device=dev),
@@ -124,7 +134,9 @@ class WGAN_GP(GAN):
     pl = plans.get(k)
     if pl is None:
       B = st['coef_gp'].shape[0]
-      pl = plans[k] = st['dws'].plan(3 * B, B, 2 * B, x0_index=k)
+      pl = plans[k] = st['dws'].plan(
+          3 * B, B, 2 * B, x0_index=k,
+          shifts=st['stage_dev'][12 * k:12 * k + 12].view(4, 3))
       pl.coef.copy_(st['critic'].coef)
       pl.bias_coef.copy_(st['critic'].bias_coef)
       pl.build_jvp(2, st['coef_gp'])
@@ -186,7 +198,8 @@ class WGAN_GP(GAN):
     # (host-drawn shifts of an eager step are a pageable temporary: a
     # non-blocking copy could read it after it is gone once the host runs ahead
     # of the GPU; the graph path hands a device view)
-    plan.shifts.copy_(shifts, non_blocking=shifts.is_cuda)
+    if shifts.data_ptr() != plan.shifts.data_ptr():  # (else staged in place)
+      plan.shifts.copy_(shifts, non_blocking=shifts.is_cuda)
     self._scale_seeds(st, 'critic', self.dis_optimizer)
     if not packed:  # (packed: plan.x0 already holds [real | fake | x^])
       if fake is None:
@@ -339,7 +352,8 @@ class WGAN_GP(GAN):
     else:
       shifts = torch.as_tensor(r['shifts'], dtype=torch.int32).reshape(4, 1)
     s = nets._stream()
-    plan.shifts.copy_(shifts, non_blocking=shifts.is_cuda)
+    if shifts.data_ptr() != plan.shifts.data_ptr():
+      plan.shifts.copy_(shifts, non_blocking=shifts.is_cuda)
     self._scale_seeds(st, 'gen', self.gen_optimizer)
     _lib.call('cg_cast_pad', nets._p(fake), nets._p(st['dws'].act[0]),
               B * lay.lin, lay.cin, self.generator.net.Cf, lay.cinp, s)
@@ -528,7 +542,7 @@ class WGAN_GP(GAN):
                     for _ in range(_STAGING_SLOTS)],
         stage_event=[None] * _STAGING_SLOTS,
         stage_next=0,
-        stage_dev=torch.zeros(n * 13 + 5, dtype=torch.int32, device=dev))
+        stage_dev=st['stage_dev'])
     g['shifts_dev'] = g['stage_dev'][:n * 12 + 4]
     g['lr_dev'] = g['stage_dev'][n * 12 + 4:].view(torch.float32)
     if g['real'].data_ptr() != real.data_ptr():

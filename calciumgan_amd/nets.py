@@ -772,25 +772,29 @@ class _DisWorkspace(object):
       alt[k] = torch.zeros_like(self.act[0])
     return alt[k]
 
-  def plan(self, nB, seg_size, input_grad_from, want_norm=True, x0_index=0):
+  def plan(self, nB, seg_size, input_grad_from, want_norm=True, x0_index=0,
+           shifts=None):
     """Descriptors for a run over the first nB samples with shift segments of
     seg_size samples; the layer-1 input gradient is computed for samples
     [input_grad_from, nB) (None = not at all).  want_norm: its per-sample sum of
     squares (the penalty norm) is taken in the same launch -- the generator
     update's pass does not need it.  x0_index: which of the step's input
-    buffers (x0(k)) the layer-1 launches read."""
+    buffers (x0(k)) the layer-1 launches read.  shifts (first use only): the int32
+    (4, segments) tensor the plan's launches read their PhaseShuffle draws from
+    (a view of the caller's staging buffer: no copy in front of a replay)."""
     key = (nB, seg_size, input_grad_from, bool(want_norm), int(x0_index))
     pl = self._plans.get(key)
     if pl is None:
       pl = _DisPlan(self, nB, seg_size, input_grad_from, want_norm,
-                    x0=self.x0(x0_index))
+                    x0=self.x0(x0_index), shifts=shifts)
       self._plans[key] = pl
     return pl
 
 
 class _DisPlan(object):
 
-  def __init__(self, ws, nB, seg_size, input_grad_from, want_norm=True, x0=None):
+  def __init__(self, ws, nB, seg_size, input_grad_from, want_norm=True, x0=None,
+               shifts=None):
     net = ws.net
     dev = net.device
     self.ws, self.nB, self.seg_size = ws, nB, seg_size
@@ -801,7 +805,11 @@ class _DisPlan(object):
     self.nseg = (nB + seg_size - 1) // seg_size
     k, pl = net.k, net.pl
     # shifts[l][seg]: PhaseShuffle draw applied after layer l+1 (l = 0..3)
-    self.shifts = torch.zeros(4, self.nseg, dtype=torch.int32, device=dev)
+    if shifts is not None:
+      assert (tuple(shifts.shape) == (4, self.nseg) and shifts.is_contiguous() and
+              shifts.dtype == torch.int32)
+    self.shifts = (shifts if shifts is not None else
+                   torch.zeros(4, self.nseg, dtype=torch.int32, device=dev))
     self.coef = torch.zeros(self.nseg, dtype=torch.float32, device=dev)
     self.bias_coef = torch.zeros(self.nseg, dtype=torch.float32, device=dev)
     self.fwd, self.dgrad, self.jvp, self.wgrad = [], [], [], []
