@@ -550,11 +550,23 @@ def _static_swp_choice(d):
   lib = _lib.load()
   saved = (d.tile, d.stage_ksteps, d.split_parity, d.ksplit)
   pick = None
-  for tile in order:
-    d.tile, d.stage_ksteps, d.split_parity, d.ksplit = tile, 2, 0, 0
+  # a launch with far fewer 256 x 64 tiles than CUs (the generator backward's
+  # first layer at B = 128: 320 -> 32 channels, 32 tiles): 128-row tiles, two
+  # workgroups per tile over halves of the channel chunks (54 -> 30 us; the one
+  # geometry of cfg2 where the static tile was not within 6 % of the tuner's
+  # best: profiles/r05_static_vs_tuned_tiles.txt)
+  tiles = ((d.nB * d.Lu + 255) // 256) * ((d.N + 63) // 64) * d.nphase
+  if (d.split_ws and tiles <= 64 and d.epilogue != _lib.EPI_LN_LRELU and
+      (d.Cx // d.CK) % 2 == 0 and not _STATIC_ORDER):
+    d.tile, d.stage_ksteps, d.split_parity, d.ksplit = 13, 2, 0, 2
     if lib.cg_swconv_check(ctypes.byref(d)) == 0:
-      pick = (tile, 2, 0, 1)
-      break
+      pick = (13, 2, 0, 2)
+  if pick is None:
+    for tile in order:
+      d.tile, d.stage_ksteps, d.split_parity, d.ksplit = tile, 2, 0, 0
+      if lib.cg_swconv_check(ctypes.byref(d)) == 0:
+        pick = (tile, 2, 0, 1)
+        break
   d.tile, d.stage_ksteps, d.split_parity, d.ksplit = saved
   return pick
 
