@@ -128,6 +128,10 @@ def algorithmic_bytes_swconv(hp, B, batched_g=False):
   critic = g_forward(False) + d_fwd(3 * B) + sum(dgrad(3 * B, l, masked=fusable(l))
                                       for l in d_l[1:])
   critic += dgrad(B, d_l[0]) + d_fwd(B)  # x^ input gradient + tangent chain
+  # (the tangent chain runs in place over the x^ segment's activations and masks
+  # with their sign: every launch also READS the bf16 activation it overwrites --
+  # counted since round 5, as tools/traffic_by_geometry.py does per launch)
+  critic += sum(B * l.lout * l.coutp * 2 for l in d_l)
   gen = g_forward(True) + d_fwd(B) + sum(dgrad(B, l, masked=fusable(l))
                                for l in d_l[1:]) + \
       dgrad(B, d_l[0]) + g_bwd
@@ -165,7 +169,9 @@ def cpu_baseline(hp, batch, steps):
       cores=torch.get_num_threads(), kind='port',
       sample='same shapes (L={}, C={}, U={}), batch {} of the benchmark batch, '
       '1 warm-up + {} timed train() steps of the torch-CPU f32 oracle '
-      '(restatement of the reference graph, not TensorFlow)'.format(
+      '(restatement of the reference graph, not TensorFlow); a reported '
+      'baseline, not the target: three steps of batch 8 on a shared host swing '
+      '0.23-1.03 samples/s between boxes of the pool (+- 2.6 x)'.format(
           hp.signal_shape[0], hp.num_channels, hp.num_units, batch, steps))
 
 

@@ -1484,6 +1484,41 @@ extern "C" long long cg_wgrad_partials_elems(const cg_wgrad_desc* d) {
   return rc ? -1 : p.part_elems;
 }
 
+// entries of a deal: the two halves' layers alternate (the rotation of the
+// kernel's item order starts neighbouring 64-id classes on different entries),
+// the shared layer last
+static bool apply_halves(const WgradPlan* np, int n, int best_s, int best_mask, int zs,
+                         WgradPlan* plans, WgradMulti& m, int& blocks, size_t& lds) {
+  constexpr int G = 128;
+  int order[kMaxBatch], half[kMaxBatch], ne = 0;
+  {
+    int a0[kMaxBatch], n0 = 0, a1[kMaxBatch], n1 = 0;
+    for (int i = 0; i < n; ++i)
+      if (i != best_s) (((best_mask >> i) & 1) ? a1[n1++] : a0[n0++]) = i;
+    for (int k = 0; k < n0 || k < n1; ++k) {
+      if (k < n0) { order[ne] = a0[k]; half[ne++] = 0; }
+      if (k < n1) { order[ne] = a1[k]; half[ne++] = 1; }
+    }
+    order[ne] = best_s; half[ne++] = 0;
+    order[ne] = best_s; half[ne++] = 1;
+  }
+  m.n = ne;
+  blocks = 2 * G;
+  lds = 0;
+  for (int e = 0; e < ne; ++e) {
+    const int i = order[e];
+    const WgradPlan& p = np[i];
+    m.a[e] = p.a;
+    m.gx[e] = p.gx; m.gy[e] = p.gy; m.gz[e] = p.nsplit; m.tt[e] = p.TT;
+    m.lo[e] = half[e] * G; m.cnt[e] = G;
+    m.zofs[e] = (i == best_s && half[e]) ? zs : 0;
+    m.zcnt[e] = i == best_s ? zs : p.nsplit;
+    if (2 * p.lds > lds) lds = 2 * p.lds;
+  }
+  for (int i = 0; i < n; ++i) plans[i] = np[i];
+  return true;
+}
+
 // "Halves" form of the batched launch (WgradMulti): deal the layers to two halves
 // of a 256-workgroup grid so that both halves carry the same multiply-adds, the
 // K' splits of one layer shared between them.  Every layer is re-planned with
@@ -1498,8 +1533,50 @@ static bool plan_halves(const cg_wgrad_desc* descs, int n, WgradPlan* plans,
     const char* e = getenv("CALCIUMGAN_WGRAD_HALVES");
     enabled = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;  // 2: print deals
   }
-  constexpr int G = 128;  // workgroups per half
+  constexpr int G = 128;  // workgroups per half (a 256-CU chip: checked below)
   if (!enabled || n < 3 || n + 1 > kMaxBatch) return false;
+  {
+    static int cus[kCgMaxDevices];  // (the halves assume 256 CUs)
+    int& c = cus[cg_device_index()];
+    if (!c && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount,
+                                    cg_device_index()) != hipSuccess)
+      c = 256;
+    if (c != 2 * G) return false;
+  }
+  // The deal is a search over split counts and layer subsets: memoised on the
+  // launch's geometry (it used to be re-derived on every eager call).
+  struct Deal { bool ok; int best_s, best_mask, zs; int nsplit[kMaxBatch]; };
+  static std::mutex deal_mutex;
+  static std::map<std::vector<long long>, Deal> deals;
+  std::vector<long long> key;
+  for (int i = 0; i < n; ++i)
+    for (long long v : {(long long)plans[i].gx, (long long)plans[i].gy, (long long)plans[i].a.M,
+                        (long long)plans[i].a.taps, (long long)plans[i].a.ntiles,
+                        (long long)plans[i].TT, (long long)descs[i].store,
+                        (long long)(plans[i].a.part != nullptr), (long long)descs[i].no_xcd_group})
+      key.push_back(v);
+  {
+    std::lock_guard<std::mutex> lock(deal_mutex);
+    auto f = deals.find(key);
+    if (f != deals.end()) {
+      const Deal& dl = f->second;
+      if (!dl.ok) return false;
+      WgradPlan np[kMaxBatch];
+      for (int i = 0; i < n; ++i) {
+        cg_wgrad_desc d = descs[i];
+        d.nsplit = dl.nsplit[i];
+        if (plan_wgrad(&d, np[i]) || np[i].nsplit != d.nsplit) return false;
+      }
+      return apply_halves(np, n, dl.best_s, dl.best_mask, dl.zs, plans, m, blocks, lds);
+    }
+  }
+  auto remember = [&](bool ok, int bs, int bm, int zs_, const WgradPlan* np) {
+    Deal dl{ok, bs, bm, zs_, {}};
+    for (int i = 0; i < n && np; ++i) dl.nsplit[i] = np[i].nsplit;
+    std::lock_guard<std::mutex> lock(deal_mutex);
+    deals[key] = dl;
+    return ok;
+  };
   double cost[kMaxBatch];
   for (int i = 0; i < n; ++i) {
     const WgradPlan& p = plans[i];
@@ -1554,39 +1631,11 @@ static bool plan_halves(const cg_wgrad_desc* descs, int n, WgradPlan* plans,
     }
   }
   // (the plain form's own figure has its idle workgroups in it: allow 4 % on top)
-  if (best_s < 0 || best > 1.04 * t_plain) return false;
+  if (best_s < 0 || best > 1.04 * t_plain) return remember(false, -1, 0, 0, nullptr);
   WgradPlan np[kMaxBatch];
   for (int i = 0; i < n; ++i) np[i] = i == best_s ? psh[i] : pex[i];
   const int zs = z_sh[best_s];
-  // entries: the two halves' layers alternate (the rotation of the kernel's item
-  // order starts neighbouring 64-id classes on different entries), the shared
-  // layer last
-  int order[kMaxBatch], half[kMaxBatch], ne = 0;
-  {
-    int a0[kMaxBatch], n0 = 0, a1[kMaxBatch], n1 = 0;
-    for (int i = 0; i < n; ++i)
-      if (i != best_s) (((best_mask >> i) & 1) ? a1[n1++] : a0[n0++]) = i;
-    for (int k = 0; k < n0 || k < n1; ++k) {
-      if (k < n0) { order[ne] = a0[k]; half[ne++] = 0; }
-      if (k < n1) { order[ne] = a1[k]; half[ne++] = 1; }
-    }
-    order[ne] = best_s; half[ne++] = 0;
-    order[ne] = best_s; half[ne++] = 1;
-  }
-  m.n = ne;
-  blocks = 2 * G;
-  lds = 0;
-  for (int e = 0; e < ne; ++e) {
-    const int i = order[e];
-    const WgradPlan& p = np[i];
-    m.a[e] = p.a;
-    m.gx[e] = p.gx; m.gy[e] = p.gy; m.gz[e] = p.nsplit; m.tt[e] = p.TT;
-    m.lo[e] = half[e] * G; m.cnt[e] = G;
-    m.zofs[e] = (i == best_s && half[e]) ? zs : 0;
-    m.zcnt[e] = i == best_s ? zs : p.nsplit;
-    if (2 * p.lds > lds) lds = 2 * p.lds;
-  }
-  for (int i = 0; i < n; ++i) plans[i] = np[i];
+  remember(true, best_s, best_mask, zs, np);
   if (enabled == 2) {
     fprintf(stderr, "cg_wgrad_batched halves: shared layer %d (2 x %d splits), half 1 = mask 0x%x, "
             "longest half %.3f of the plain form's time; splits", best_s, zs, best_mask,
@@ -1594,7 +1643,7 @@ static bool plan_halves(const cg_wgrad_desc* descs, int n, WgradPlan* plans,
     for (int i = 0; i < n; ++i) fprintf(stderr, " %d", np[i].nsplit);
     fprintf(stderr, "\n");
   }
-  return true;
+  return apply_halves(np, n, best_s, best_mask, zs, plans, m, blocks, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -1848,6 +1897,15 @@ int launch_flex(const WgradFlex& m, int blocks, size_t lds, hipStream_t s) {
 int run_flex(const cg_wgrad_desc* descs, int n, WgradPlan* plans, hipStream_t s) {
   const int mode = flex_mode();
   if (!mode || n > kMaxBatch) return -1;
+  {
+    // (the share plan fills 256 workgroups, one per CU, 32 per XCD: MI355X)
+    static int cus[kCgMaxDevices];
+    int& c = cus[cg_device_index()];
+    if (!c && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount,
+                                    cg_device_index()) != hipSuccess)
+      c = 256;
+    if (c != 256) return -1;
+  }
   for (int i = 0; i < n; ++i) {
     const WgradPlan& p = plans[i];
     if (!p.a.ring || p.tpw != 3 || !descs[i].partials) return -1;
