@@ -554,7 +554,9 @@ def _static_swp_choice(d):
   # first layer at B = 128: 320 -> 32 channels, 32 tiles): 128-row tiles, two
   # workgroups per tile over halves of the channel chunks (54 -> 30 us; the one
   # geometry of cfg2 where the static tile was not within 6 % of the tuner's
-  # best: profiles/r05_static_vs_tuned_tiles.txt)
+  # best: profiles/r05_static_vs_tuned_tiles.txt; 128-column tiles for the
+  # under-filled launches with wide outputs, 3-6 % ahead in that table, were
+  # worth 0.1 % of the step in a same-box A/B and are not a rule)
   tiles = ((d.nB * d.Lu + 255) // 256) * ((d.N + 63) // 64) * d.nphase
   if (d.split_ws and tiles <= 64 and d.epilogue != _lib.EPI_LN_LRELU and
       (d.Cx // d.CK) % 2 == 0 and not _STATIC_ORDER):
