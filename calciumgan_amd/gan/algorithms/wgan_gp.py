@@ -144,12 +144,14 @@ class WGAN_GP(GAN):
         pl.defer_norm()
     return pl
 
-  def _can_fuse_interp(self, B, n):
+  def _can_fuse_interp(self, B, n, gws=None):
     """cg_dense_rows_interp applies: bf16 build (no loss scale on the seeds), the
-    register form of the output Dense, n <= 8 updates."""
+    register form of the output Dense, n <= 8 updates.  gws: the generator
+    workspace of the pass (default: the forward-only one over n * B samples)."""
     if not _FUSE_INTERP or self.dis_optimizer.loss_scale is not None:
       return False
-    gws = self.generator.net.workspace(n * B, forward_only=True)
+    if gws is None:
+      gws = self.generator.net.workspace(n * B, forward_only=True)
     lay = self.discriminator.net.layers[0]
     return gws.can_interp(n) and lay.cinp == self.generator.net.Cp
 
@@ -408,6 +410,22 @@ class WGAN_GP(GAN):
 
     def generate(key, r):
       def run():
+        B = real.shape[0]
+        if key != 'g' and self._can_fuse_interp(B, 1, st['gws']):
+          # a critic update's own generator pass (data parallel, BatchNorm,
+          # CALCIUMGAN_BATCH_G=0): its output Dense writes [real | fake | x^]
+          # into X0 itself (cg_dense_rows_interp, n = 1) -- no f32 fake batch, no
+          # cg_interp_pack.  X0 is free: every launch of the previous update that
+          # read it is ahead of this one on the stream
+          drawn = r is None or 'shifts_dev' in r
+          z = self.get_noise(B) if drawn else self._to_device(r['z'])
+          a = (self._streams.alpha(B) if drawn
+               else self._to_device(r['alpha']).reshape(-1))
+          st['gws'].forward(z, keep=False, interp=(real, a, [st['dws'].x0(0)]))
+          box[key] = None
+          box[('alpha', key)] = a
+          box[('packed', key)] = True
+          return
         # only the generator update's own forward ('g') is followed by a
         # backward through G
         box[key] = self._critic_generate(real, r, keep=key == 'g')
@@ -422,7 +440,9 @@ class WGAN_GP(GAN):
         self._critic_compute(real, rc(i), slot=i, real_cached=i > 0,
                              fake=None if own_g else box.pop(i),
                              alpha=box.pop(('alpha', i), None),
-                             x0_index=i if box.get('packed') else None)
+                             x0_index=(i if box.get('packed') else
+                                       0 if box.pop(('packed', i), False)
+                                       else None))
       return run
 
     def gen_seg():
@@ -443,9 +463,13 @@ class WGAN_GP(GAN):
       out['value'] = o
 
     segs = []
+    def first_seg():
+      generate(0, rc(0))()
+      critic_seg(0, False)()
+
     for i in range(n):
       if i == 0:
-        segs.append((critic_seg(0, True), d_grad, False))
+        segs.append((first_seg, d_grad, False))
       else:
         segs.append((generate(i, rc(i)), None, False))
         segs.append((critic_seg(i, False), d_grad, True))

@@ -102,13 +102,17 @@ def test_fused_penalty_launch_equals_the_three_launches_bit_for_bit():
   assert a['weights'] == b['weights']
 
 
-def test_fused_interpolation_equals_the_separate_launches_bit_for_bit():
-  """cg_dense_rows_interp (round 5: the batched generator pass writes every critic
-  update's [real | fake | x^] itself) against cg_dense_rows + n_critic
-  cg_interp_pack launches (CALCIUMGAN_FUSE_INTERP=0): the same arithmetic on the
-  same draws, so ten steps at cfg2's layer shapes end on identical bits."""
+@pytest.mark.parametrize('extra', [{}, {'CALCIUMGAN_BATCH_G': '0'},
+                                   {'CALCIUMGAN_SPLIT_SEGMENTS': '1'}],
+                         ids=['batched_pass', 'pass_per_update', 'dp_segments'])
+def test_fused_interpolation_equals_the_separate_launches_bit_for_bit(extra):
+  """cg_dense_rows_interp (round 5: the generator pass writes the critic's
+  [real | fake | x^] itself -- all updates' at once from the batched pass, one
+  update's from a per-update pass as under data parallelism) against
+  cg_dense_rows + cg_interp_pack (CALCIUMGAN_FUSE_INTERP=0): the same arithmetic
+  on the same draws, so ten steps at cfg2's layer shapes end on identical bits."""
   shape = (2048, 102, 16, 4)
-  a = _run(10, shape)
-  b = _run(10, shape, {'CALCIUMGAN_FUSE_INTERP': '0'})
+  a = _run(10, shape, dict(extra))
+  b = _run(10, shape, dict(extra, CALCIUMGAN_FUSE_INTERP='0'))
   assert a['outputs'] == b['outputs'], (a['last'], b['last'])
   assert a['weights'] == b['weights']
