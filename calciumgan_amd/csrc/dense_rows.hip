@@ -307,8 +307,11 @@ struct DenseWideArgs {
   int Cx, N, Cy, epilogue, out_act, panels;
 };
 
+// (K = 128: the panel is 34 KB and the fragment sets 230 registers -- two
+// workgroups per CU, twice the loads in flight: the cfg2 input gradient of the
+// output Dense is latency-bound at one wave per SIMD, 2.8 TB/s)
 template <int KSTEPS>
-__global__ __launch_bounds__(kWideThreads, 1) void dense_rows_wide_kernel(
+__global__ __launch_bounds__(kWideThreads, KSTEPS <= 4 ? 2 : 1) void dense_rows_wide_kernel(
     DenseWideArgs a) {
   constexpr int kRowB = KSTEPS * 64 + 16;  // LDS bytes per W column (k-major)
   extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
@@ -470,8 +473,8 @@ int launch_dense_wide(const DenseWideArgs& a, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_set.mark();
   }
-  // one workgroup per CU: 256 = 8 XCDs x (32 / panels) row groups x panels
-  const int per_xcd = 32 / a.panels * a.panels;
+  // one workgroup per CU (two at K = 128): 8 XCDs x (32 / panels) row groups x panels
+  const int per_xcd = (KSTEPS <= 4 ? 64 : 32) / a.panels * a.panels;
   hipLaunchKernelGGL(dense_rows_wide_kernel<KSTEPS>, dim3(8 * per_xcd),
                      dim3(kWideThreads), lds, s, a);
   CG_LAUNCH_CHECK();

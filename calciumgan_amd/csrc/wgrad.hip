@@ -1867,6 +1867,12 @@ FlexPlan* flex_plan_for(const WgradPlan* plans, int n, int mode, hipStream_t s) 
       (void)hipGetLastError();
       fp->ok = false;
     }
+    // (the table is shared by every later launch of this geometry, on whatever
+    // stream: outside a capture, wait for the copy once)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (fp->ok && hipStreamIsCapturing(s, &cs) == hipSuccess &&
+        cs == hipStreamCaptureStatusNone)
+      (void)hipStreamSynchronize(s);
     if (fp->ok && flex_env("CALCIUMGAN_WGRAD_FLEX_PRINT", 0)) {
       fprintf(stderr, "cg_wgrad_batched flex: %d layers, teams of %d x %d, %d workgroups, %d items, slots",
               n, fp->S, fp->nteams, fp->nwg, fp->nitems);
