@@ -117,6 +117,8 @@ SIGNATURES = {
     'cg_swconv_check': [C.POINTER(ConvDesc)],
     'cg_rowsumsq_ws_elems': [C.POINTER(ConvDesc)],
     'cg_reduce_ws_elems': [],
+    'cg_finish_defer': [c_i],
+    'cg_finish_flush': [c_vp],
     'cg_dense_rows': [c_vp, c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_i, c_vp],
     'cg_dense_rows_interp': [c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(c_vp), c_i, c_i,
                              c_i, c_i, c_i, c_i, c_i, c_i, c_vp],

@@ -71,7 +71,71 @@ __global__ __launch_bounds__(1024) void finish_cols_kernel(FinishArgs f) {
   }
 }
 
+// Deferred finishing launches (round 5).  The finishing launch of a reduction
+// whose result only the optimizer reads -- the generator backward's seven: bias,
+// gamma / beta gradients -- does not have to sit between its producer and the
+// next kernel of the chain: between cg_finish_defer(1) and cg_finish_flush() on a
+// thread every launch_finish is queued, and the flush adds all of them in ONE
+// launch (same order of sums per output: same bits).  The caller gives every
+// queued reduction its OWN workspace region (the partial rows must survive until
+// the flush).
+constexpr int kMaxDeferred = 12;
+struct FinishBatch {
+  int n;
+  FinishArgs f[kMaxDeferred];
+};
+thread_local bool g_finish_defer = false;
+thread_local FinishBatch g_finish_batch;
+
+__global__ __launch_bounds__(1024) void finish_cols_batched_kernel(FinishBatch b) {
+  const FinishArgs& f = b.f[blockIdx.z];
+  if ((int)blockIdx.y >= f.nout || (int)blockIdx.x * 64 >= f.ncol) return;
+  __shared__ float sm[16][64];
+  const int lane = threadIdx.x & 63;
+  const int j = threadIdx.x >> 6;
+  const int o = blockIdx.y;
+  const int c = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < f.ncol) {
+    const float* p = f.ws + (long long)o * f.cstride + c;
+    int r = j;
+    for (; r + 112 < f.nparts; r += 128) {
+      float a[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] = p[(long long)(r + 16 * k) * f.pstride];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += a[k];
+    }
+    for (; r < f.nparts; r += 16) s += p[(long long)r * f.pstride];
+  }
+  sm[j][lane] = s;
+  __syncthreads();
+  if (j == 0 && c < f.cvalid[o]) {
+    float t = sm[0][lane];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sm[k][lane];
+    f.out[o][c] = t * f.scale;
+  }
+}
+
+inline void flush_finishes(hipStream_t s) {
+  FinishBatch& b = g_finish_batch;
+  if (b.n == 0) return;
+  int gx = 1, gy = 1;
+  for (int i = 0; i < b.n; ++i) {
+    if ((b.f[i].ncol + 63) / 64 > gx) gx = (b.f[i].ncol + 63) / 64;
+    if (b.f[i].nout > gy) gy = b.f[i].nout;
+  }
+  hipLaunchKernelGGL(finish_cols_batched_kernel, dim3(gx, gy, b.n), dim3(1024), 0, s, b);
+  b.n = 0;
+}
+
 inline void launch_finish(const FinishArgs& f, hipStream_t s) {
+  if (g_finish_defer) {
+    if (g_finish_batch.n == kMaxDeferred) flush_finishes(s);
+    g_finish_batch.f[g_finish_batch.n++] = f;
+    return;
+  }
   hipLaunchKernelGGL(finish_cols_kernel, dim3((f.ncol + 63) / 64, f.nout),
                      dim3(1024), 0, s, f);
 }
@@ -1411,6 +1475,19 @@ extern "C" int cg_ln_lrelu_fwd(const void* y_pre, const float* gamma,
 }
 
 extern "C" long long cg_reduce_ws_elems(void) { return kReduceWsElems; }
+
+extern "C" int cg_finish_defer(int on) {
+  const int was = g_finish_defer ? 1 : 0;
+  if (on && !g_finish_defer) g_finish_batch.n = 0;
+  g_finish_defer = on != 0;
+  return was;
+}
+
+extern "C" int cg_finish_flush(void* stream) {
+  flush_finishes(S_(stream));
+  g_finish_defer = false;
+  CG_LAUNCH_CHECK();
+}
 
 extern "C" int cg_ln_lrelu_bwd(const void* dh, const void* h, const void* y_pre,
                                const float* mean, const float* rstd,

@@ -134,6 +134,26 @@ def reduce_ws(device):
   return ws
 
 
+# CALCIUMGAN_DEFER_FINISH=0: every ordered reduction of the generator backward is
+# finished by its own launch instead of one launch for all of them (A/B)
+_DEFER_FINISH = __import__('os').environ.get('CALCIUMGAN_DEFER_FINISH', '1') != '0'
+_REDUCE_WS_REGIONS = {}
+
+
+def reduce_ws_regions(device, n):
+  """n workspaces of the ordered reductions for reductions whose finishing
+  launches are deferred to ONE launch (cg_finish_defer / cg_finish_flush): each
+  keeps its partial rows until the flush.  Per device, precision and stream."""
+  key = (str(device), _lib.active(),
+         torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
+  ws = _REDUCE_WS_REGIONS.get(key)
+  if ws is None or ws.shape[0] < n:
+    per = _lib.load().cg_reduce_ws_elems()
+    ws = _REDUCE_WS_REGIONS[key] = torch.empty(n, per, dtype=torch.float32,
+                                               device=device)
+  return ws
+
+
 # CALCIUMGAN_NARROW_LAST=0: padded channel chunks are walked in full
 _NARROW_LAST = __import__('os').environ.get('CALCIUMGAN_NARROW_LAST', '1') != '0'
 
@@ -1322,6 +1342,25 @@ class _GenWorkspace(object):
     gradient into params.grad (caller zeroed it)."""
     net = self.net
     st = _stream()
+    # the bias / gamma / beta column sums below are read by nobody before the
+    # optimizer: their seven finishing launches become one (cg_finish_defer),
+    # each reduction with its own workspace region.  (BatchNormalization's
+    # backward reads its sums at once: not deferred.)
+    defer = (_DEFER_FINISH and DETERMINISTIC and net.layer_norm and
+             not net.batch_norm and self.h[0].is_cuda)
+    if defer:
+      regions = reduce_ws_regions(net.device, len(net.layers) + 2)
+      _lib.load().cg_finish_defer(1)
+      try:
+        self._backward(dfake, st, lambda k: _p(regions[k]))
+      finally:
+        _lib.call('cg_finish_flush', st)
+    else:
+      rws = _p(reduce_ws(net.device))
+      self._backward(dfake, st, lambda k: rws)
+
+  def _backward(self, dfake, st, rws_of):
+    net = self.net
     G = net.params.grad_views
     V = net.params.views
     rows = self.B * net.L
@@ -1335,9 +1374,9 @@ class _GenWorkspace(object):
     _lib.call('cg_dense_wgrad', _p(self.h[-1]), _p(self.dz), _p(G[net.idx_out]),
               rows, net.Cp, net.Cp, net.C, net.C, _p(self.out_wgrad_ws),
               0 if self.out_wgrad_ws is None else self.out_wgrad_ws.numel(), st)
-    rws = _p(reduce_ws(net.device))
+    nl = len(net.layers)
     _lib.call('cg_colsum', _p(self.dz), _p(G[net.idx_out + 1]), rows, net.C,
-              net.Cp, rws, st)
+              net.Cp, rws_of(nl), st)
     if net.streaming_out_dgrad:
       _lib.call('cg_dense_rows_act', _p(self.dz), _p(net.w_out_t.buf),
                 _p(self.dh[-1]), rows, net.Cp, net.C, net.Cp, st)
@@ -1355,35 +1394,35 @@ class _GenWorkspace(object):
                     _p(self.ybn[i + 1]), _p(self.mean[i + 1]),
                     _p(self.rstd[i + 1]), _p(V[il]), _p(self.dybn[i + 1]),
                     _p(G[il]), _p(G[il + 1]), None, n, lay.cout, lay.coutp,
-                    net.alpha, rws, st)
+                    net.alpha, rws_of(i), st)
           dout, hmask, act = self.dybn[i + 1], None, 0
         _lib.call('cg_bn_bwd', _p(dout), _p(hmask), _p(self.ypre[i + 1]),
                   _p(self.bn_mean[i + 1]), _p(self.bn_var[i + 1]), _p(V[ib]),
                   _p(self.dy[i + 1]), _p(G[ib]), _p(G[ib + 1]), n, lay.cout,
-                  lay.coutp, BN_EPS, net.alpha, act, rws, st)
+                  lay.coutp, BN_EPS, net.alpha, act, rws_of(i), st)
         # (the conv bias gradient: BatchNormalization removes the column mean, so
         # this sum is zero up to rounding -- as the reference's autodiff gives it)
         _lib.call('cg_colsum', _p(self.dy[i + 1]), _p(G[ic + 1]), n, lay.cout,
-                  lay.coutp, rws, st)
+                  lay.coutp, rws_of(i), st)
       elif net.layer_norm:
         il = net.idx_ln[i]
         _lib.call('cg_ln_lrelu_bwd', _p(self.dh[i + 1]), _p(self.h[i + 1]),
                   _p(self.ypre[i + 1]), _p(self.mean[i + 1]),
                   _p(self.rstd[i + 1]), _p(V[il]), _p(self.dy[i + 1]),
                   _p(G[il]), _p(G[il + 1]), _p(G[ic + 1]), n, lay.cout,
-                  lay.coutp, net.alpha, rws, st)
+                  lay.coutp, net.alpha, rws_of(i), st)
       else:
         _lib.call('cg_lrelu_bwd', _p(self.dh[i + 1]), _p(self.h[i + 1]),
                   _p(self.dy[i + 1]), n * lay.coutp, net.alpha, st)
         _lib.call('cg_colsum', _p(self.dy[i + 1]), _p(G[ic + 1]), n, lay.cout,
-                  lay.coutp, rws, st)
+                  lay.coutp, rws_of(i), st)
       _run_conv(self.b_dgrad[i], st)
     nflat = net.w0 * net.nd
     _lib.call('cg_lrelu_bwd', _p(self.dh[0]), _p(self.h[0]), _p(self.dy[0]),
               self.B * nflat, net.alpha, st)
     _run_wgrad(self.b_in_wgrad, st)
-    _lib.call('cg_colsum', _p(self.dy[0]), _p(G[1]), self.B, nflat, nflat, rws,
-              st)
+    _lib.call('cg_colsum', _p(self.dy[0]), _p(G[1]), self.B, nflat, nflat,
+              rws_of(nl + 1), st)
     # the conv-transpose weight gradients read h[i] / dy[i+1], which the chain
     # above only produced: all of them together, at the end
     _run_wgrads(self.b_wgrad, st)

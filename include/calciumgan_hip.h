@@ -389,6 +389,15 @@ int cg_ln_lrelu_fwd(const void* y_pre /*bf16 [rows][Cp]*/, const float* gamma,
  * output.  ws == NULL: blocks meet through f32 atomics (+= into outputs the
  * caller zeroed; the order, and so the last bits, vary from run to run). */
 long long cg_reduce_ws_elems(void);
+/* Deferred finishing launches (round 5): between cg_finish_defer(1) and
+ * cg_finish_flush(stream) on the calling thread, the finishing launch of every
+ * ordered reduction above is queued instead of issued, and the flush adds all
+ * queued reductions in ONE launch (up to 12 per launch; the same sums in the same
+ * order).  Every queued call must have been given its own workspace region -- its
+ * partial rows are read at the flush -- and nothing between may read the outputs
+ * (cg_bn_bwd does: not deferrable).  cg_finish_defer returns the previous mode. */
+int cg_finish_defer(int on);
+int cg_finish_flush(void* stream);
 /* dy = d(loss)/d(y_pre); dgamma/dbeta (and, when dbias != NULL, the bias
  * gradient of the producing conv = column sums of dy): stored (ws) or
  * accumulated with f32 atomics (ws == NULL). */

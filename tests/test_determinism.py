@@ -69,7 +69,8 @@ def test_atomics_form_is_still_available_and_close():
     'CALCIUMGAN_SPLIT_SEGMENTS=1', 'CALCIUMGAN_SWP_LEAN_EPI=1',
     # round 5
     'CALCIUMGAN_WGRAD_FLEX=0', 'CALCIUMGAN_SWP_CHUNK_INNER=0',
-    'CALCIUMGAN_FUSE_INTERP=0', 'CALCIUMGAN_LN_POW2=1', 'CALCIUMGAN_AUTOTUNE=1'])
+    'CALCIUMGAN_FUSE_INTERP=0', 'CALCIUMGAN_LN_POW2=1', 'CALCIUMGAN_AUTOTUNE=1',
+    'CALCIUMGAN_DEFER_FINISH=0'])
 def test_every_documented_switch_is_a_working_configuration(knob):
   """README's switches select older / alternative forms of the same arithmetic.
   Each must still train: the first train() call (five critic updates + one
@@ -114,5 +115,16 @@ def test_fused_interpolation_equals_the_separate_launches_bit_for_bit(extra):
   shape = (2048, 102, 16, 4)
   a = _run(10, shape, dict(extra))
   b = _run(10, shape, dict(extra, CALCIUMGAN_FUSE_INTERP='0'))
+  assert a['outputs'] == b['outputs'], (a['last'], b['last'])
+  assert a['weights'] == b['weights']
+
+
+def test_deferred_finishing_launches_equal_the_separate_ones_bit_for_bit():
+  """cg_finish_defer / cg_finish_flush (round 5: the seven finishing launches of
+  the generator backward's ordered reductions as one) against one finishing launch
+  per reduction (CALCIUMGAN_DEFER_FINISH=0): the same sums in the same order."""
+  shape = (2048, 102, 16, 4)
+  a = _run(10, shape)
+  b = _run(10, shape, {'CALCIUMGAN_DEFER_FINISH': '0'})
   assert a['outputs'] == b['outputs'], (a['last'], b['last'])
   assert a['weights'] == b['weights']
