@@ -145,10 +145,10 @@ class WGAN_GP(GAN):
     return pl
 
   def _can_fuse_interp(self, B, n, gws=None):
-    """cg_dense_rows_interp applies: bf16 build (no loss scale on the seeds), the
-    register form of the output Dense, n <= 8 updates.  gws: the generator
-    workspace of the pass (default: the forward-only one over n * B samples)."""
-    if not _FUSE_INTERP or self.dis_optimizer.loss_scale is not None:
+    """cg_dense_rows_interp applies: the register form of the output Dense (pitch
+    128), n <= 8 updates.  gws: the generator workspace of the pass (default: the
+    forward-only one over n * B samples)."""
+    if not _FUSE_INTERP:
       return False
     if gws is None:
       gws = self.generator.net.workspace(n * B, forward_only=True)
@@ -170,15 +170,17 @@ class WGAN_GP(GAN):
                                     dtype=torch.float32, device=self.device)
     return st['batch_buf']
 
-  def _scale_seeds(self, st, which, optimizer):
-    """coef = base * (S where the segment's loss term is scaled, else 1)."""
+  def _scale_seeds(self, st, which, optimizer, plan=None):
+    """coef = base * (S where the segment's loss term is scaled, else 1), on the
+    plan the coming launches use (default: st[which])."""
     S = optimizer.loss_scale
     if S is None:
       return
+    plan = st[which] if plan is None else plan
     coef, bias_coef, scaled = st['coef_base'][which]
     f = scaled * S + (1.0 - scaled)
-    torch.mul(coef, f, out=st[which].coef)
-    torch.mul(bias_coef, f, out=st[which].bias_coef)
+    torch.mul(coef, f, out=plan.coef)
+    torch.mul(bias_coef, f, out=plan.bias_coef)
 
   # -- losses (API parity; the fused kernels compute the same values) ---------
   def generator_loss(self, fake_output):
@@ -202,7 +204,7 @@ class WGAN_GP(GAN):
     # of the GPU; the graph path hands a device view)
     if shifts.data_ptr() != plan.shifts.data_ptr():  # (else staged in place)
       plan.shifts.copy_(shifts, non_blocking=shifts.is_cuda)
-    self._scale_seeds(st, 'critic', self.dis_optimizer)
+    self._scale_seeds(st, 'critic', self.dis_optimizer, plan)
     if not packed:  # (packed: plan.x0 already holds [real | fake | x^])
       if fake is None:
         fake = st['gws'].forward(z, keep=False, training=training)
