@@ -171,7 +171,7 @@ def cpu_baseline(hp, batch, steps):
       '1 warm-up + {} timed train() steps of the torch-CPU f32 oracle '
       '(restatement of the reference graph, not TensorFlow); a reported '
       'baseline, not the target: three steps of batch 8 on a shared host swing '
-      '0.23-1.03 samples/s between boxes of the pool (+- 2.6 x)'.format(
+      '0.23-1.10 samples/s between boxes of the pool (+- 2.6 x)'.format(
           hp.signal_shape[0], hp.num_channels, hp.num_units, batch, steps))
 
 
