@@ -1692,9 +1692,16 @@ struct FlexCol {
 // plans[i]: the standard plan of layer i (geometry only is read)
 void plan_flex(const WgradPlan* plans, int n, int mode, FlexPlan& fp) {
   fp.ok = false;
-  // cost of a K' tile in team time: 64-row tiles pay the per-tile barrier and the
-  // DMA issue twice per 128 rows
-  const int c128 = 16, c64 = flex_env("CALCIUMGAN_WGRAD_FLEX_C64", 9);
+  // cost of a K' tile in team time, from the in-kernel trace of the cfg2 critic
+  // pass (tools/wgrad_trace.py, profiles/r05_wgrad_flex_trace.txt: K' loop cycles
+  // per tile 4141 / 4361 / 4324 / 4274 for the four layers with 128-row tiles,
+  // 2517 for the 64-row tiles of the last): 64-row tiles pay the per-tile barrier
+  // and the DMA issue twice per 128 rows (0.59, not 0.5); the layer without a
+  // PhaseShuffle in front of it, whose tiles are mostly interior, runs 3-5 % under
+  // the others
+  const int c128 = flex_env("CALCIUMGAN_WGRAD_FLEX_C128", 64);
+  const int c64 = flex_env("CALCIUMGAN_WGRAD_FLEX_C64", 38);
+  const int cplain = flex_env("CALCIUMGAN_WGRAD_FLEX_CPLAIN", 62);
   const int snap = flex_env("CALCIUMGAN_WGRAD_FLEX_SNAP", 4);
   const long long min_share = 8 * c128;  // a team's share must be worth its set-up
   // team size: the largest whose padded columns cost at most 5 % over the best
@@ -1722,7 +1729,7 @@ void plan_flex(const WgradPlan* plans, int n, int mode, FlexPlan& fp) {
           bcols = nc; bbytes = bytes; bcw = cw; bch = ch;
         }
       }
-      const long long cost = p.TT == 128 ? c128 : c64;
+      const long long cost = p.TT == 128 ? (p.a.shifts ? c128 : cplain) : c64;
       for (int by0 = 0; by0 < p.gy; by0 += bch)
         for (int bx0 = 0; bx0 < p.gx; bx0 += bcw) {
           cols.push_back(FlexCol{i, bcw, bch, bx0, by0, (long long)p.a.ntiles, cost});

@@ -38,7 +38,10 @@ def _desc(nB, Lx, Cin, Cout):
 
 def _critic(nB, L, C, U):
   chans = [C, U, 2 * U, 3 * U, 4 * U, 5 * U]
-  return [_desc(nB, L >> i, chans[i], chans[i + 1]) for i in range(5)]
+  descs = [_desc(nB, L >> i, chans[i], chans[i + 1]) for i in range(5)]
+  for d in descs[1:]:  # PhaseShuffle in front of layers 2-5 (calciumgan.py:117-138)
+    d.shifts, d.seg_size = 0x1000, max(1, nB // 3)
+  return descs
 
 
 def _generator(nB, L, C, U):
@@ -80,7 +83,10 @@ def _check(descs, mode):
       assert 0 <= li < len(descs) and 0 <= bx < grids[li][0] and 0 <= by < grids[li][1]
       assert kn > 0 and k0 >= 0 and k0 + kn <= ntiles[li]
       per_tile.setdefault((li, bx, by), []).append((k0, kn, slot))
-      cost[w] += kn * (16 if descs[li].Lu % 128 == 0 else 9)
+      # (the planner's costs: 64 per 128-row tile -- 62 without a PhaseShuffle in
+      # front of the layer --, 38 per 64-row tile)
+      cost[w] += kn * ((64 if descs[li].shifts else 62) if descs[li].Lu % 128 == 0
+                       else 38)
       count += 1
   assert count == nitems
   slots = [0] * len(descs)

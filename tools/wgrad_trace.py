@@ -44,6 +44,7 @@ def main():
     print('  %-44s %9.0f cycles  %5.1f %%   %7.0f per layer'
           % (name, w[:, k].mean(), 100 * w[:, k].mean() / tot.mean(), w[:, k].mean() / 5))
   per_wg(t)
+  per_layer(gan, t)
 
 
 def per_wg(t):
@@ -53,6 +54,44 @@ def per_wg(t):
   kl = t[:, :, 1].mean(-1)
   print("  K' loop only:")
   print('   ', ' '.join('%4.0f' % (kl[i:i + 16].mean() / 1e3) for i in range(0, 256, 16)))
+
+
+def per_layer(gan, t):
+  """Flex form (round 5): the wave life of the workgroups by the layer their
+  share lies in (workgroups whose items are all of one layer), and the K' loop
+  cycles per K' tile of that layer -- what the planner's per-tile costs (16 per
+  128-row tile, 9 per 64-row tile) should be proportional to."""
+  lib = _lib.load()
+  descs = gan._get_state(128)['critic'].wgrad
+  arr = (_lib.WgradDesc * len(descs))(*descs)
+  info = (ctypes.c_int * 16)()
+  n = lib.cg_wgrad_flex_plan(arr, len(descs), 1, None, 0, info)
+  if n < 0:
+    print('  (not the flex form)')
+    return
+  out = (ctypes.c_int * n)()
+  lib.cg_wgrad_flex_plan(arr, len(descs), 1, out, n, info)
+  nwg = info[2]
+  items = np.array(out[:nwg * 48]).reshape(nwg, 8, 6)
+  life = t.sum(-1).mean(-1)
+  kloop = t[:, :, 1].mean(-1)
+  print('  flex form: teams of %d, %d items; by the layer a workgroup\'s share lies in:' % (
+      info[0], info[3]))
+  for li in range(len(descs)):
+    sel, tiles = [], []
+    for w in range(min(nwg, 256)):
+      its = [r for r in items[w] if r[0] >= 0]
+      if its and all(r[0] == li for r in its):
+        sel.append(w)
+        tiles.append(sum(int(r[4]) for r in its))
+    if not sel:
+      continue
+    sel = np.array(sel)
+    print('    layer %d: %3d workgroups, life %6.0f k cycles (min %.0f max %.0f), K\' loop '
+          '%6.0f k = %5.0f cycles per K\' tile (%d tiles each)' % (
+              li + 1, len(sel), life[sel].mean() / 1e3, life[sel].min() / 1e3,
+              life[sel].max() / 1e3, kloop[sel].mean() / 1e3,
+              kloop[sel].mean() / np.mean(tiles), int(np.mean(tiles))))
 
 
 if __name__ == '__main__':
