@@ -313,7 +313,7 @@ template <int TT>
 __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
                                                 unsigned char* smem, int bx,
                                                 int by, int bz, int gz, int tn,
-                                                bool do_bias,
+                                                bool do_bias, int bias_cw, int bias_m,
                                                 f32x4 (&acc)[3][2][4],
                                                 float& bs0, float& bs1
                                                 CG_WTR_PARAMS) {
@@ -522,32 +522,46 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
     });
     lds_wait_set(f, SET ^ 1);
   };
-  // bias gradient: column sums of the g tile in slot `soff` (asm reads, as the
-  // fragments: consumed after the phase's wait)
-  constexpr int RPG = TT / 16;
-  const int cp = (tid & 31) * 2;
-  const int cs_row = (tid >> 5) * RPG;
-  uint32_t csw[RPG];
-  auto colsum_read = [&](int soff) {
-#pragma unroll
-    for (int k = 0; k < RPG; ++k) {
-      const int row = cs_row + k;
-      const int addr = lds0 + soff + G::XB + row * 128 +
-                       (((cp >> 4) ^ ((row >> 1) & 3)) * 32) + (cp & 15) * 2;
-      asm volatile("ds_read_b32 %0, %1" : "=v"(csw[k]) : "v"(addr));
-    }
+  // bias gradient: the column sums of the g tiles come out of the g FRAGMENTS the
+  // MFMAs read anyway (round 5).  Lane (n = lane & 15, k-group lane >> 4) of a B
+  // fragment holds 8 k-values of column nt * 16 + n: wave w adds those of column
+  // block nt = w & 3 for the K-steps k with (k & 1) == (w >> 2) -- every (K-step,
+  // column block) of a tile has exactly one wave -- into ONE float per lane; the
+  // lane groups and the two waves of a column block meet once per item (wgrad_body).
+  // No extra LDS read: the separate column-sum reads (8 ds_read_b32 per thread and
+  // tile) made the workgroups of cx block 0 live 8 % longer than the others, and
+  // the launch ended with them (profiles/r05_wgrad_flex_trace.txt).
+  // (bias_rows is a multiple of 32: checked on the host)
+  const int bnt = wave & 3, bhalf = wave >> 2;
+  // (v_dot2c_f32_{bf16,f16} against (1, 1): two activations into an f32 sum per
+  // instruction, two independent chains -- 4 VALU per fragment pair instead of 16)
+  auto dot_ones = [](uint32_t v, float c) {
+#if CG_ACT_F16
+    typedef __attribute__((ext_vector_type(2))) _Float16 a2;
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(a2, v),
+                                  __builtin_bit_cast(a2, 0x3c003c00u), c, false);
+#else
+    typedef __attribute__((ext_vector_type(2))) __bf16 a2;
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(a2, v),
+                                           __builtin_bit_cast(a2, 0x3f803f80u), c, false);
+#endif
   };
-  auto colsum_add = [&](int tile) {
-    // (called behind the wait of the step that followed colsum_read: these
-    // statements keep the sums below from moving in front of that wait)
-#pragma unroll
-    for (int k = 0; k < RPG; ++k) asm volatile("" : "+v"(csw[k]));
-#pragma unroll
-    for (int k = 0; k < RPG; ++k)
-      if ((long long)tile * TT + cs_row + k < a.bias_rows) {
-        bs0 += act_lo(csw[k]);
-        bs1 += act_hi(csw[k]);
-      }
+  auto frag_sum = [&](const s16x4& lo, const s16x4& hi) {
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+    const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
+    bs0 = dot_ones(l[0], bs0);
+    bs1 = dot_ones(l[1], bs1);
+    bs0 = dot_ones(h[0], bs0);
+    bs1 = dot_ones(h[1], bs1);
+  };
+  auto frag_colsum = [&](auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+    switch (bnt) {  // (wave-uniform: a register array cannot be indexed at run time)
+      case 0: frag_sum(f.bl[SET][0], f.bh[SET][0]); break;
+      case 1: frag_sum(f.bl[SET][1], f.bh[SET][1]); break;
+      case 2: frag_sum(f.bl[SET][2], f.bh[SET][2]); break;
+      default: frag_sum(f.bl[SET][3], f.bh[SET][3]); break;
+    }
   };
 
   // ---- prologue: NS tiles in flight, fragments of tile 0 / step 0 -------------
@@ -566,17 +580,19 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
     int soff = 0;  // ring slot (byte offset) of tile i
     for (int i = 0; i < n_i; ++i) {
       const int tile = bz + i * gz;
-      const bool bias_tile = do_bias && (long long)tile * TT < a.bias_rows;
-      if (bias_tile) colsum_read(soff);
+      const long long trow = (long long)tile * TT;
+      // (flex form: the bias_cw team members that stream the same g tiles take
+      // the column sums of every bias_cw-th tile each)
+      const bool bias_tile =
+          do_bias && (tile & (bias_cw - 1)) == bias_m && trow < a.bias_rows;
       static_for<KSTEPS>([&](auto k_tag) {
         constexpr int k = decltype(k_tag)::value;
         using SET = integral_constant<int, k & 1>;
+        // this wave's share of the bias column sums: K-step k's g fragments
+        const bool bsum = bias_tile && (k & 1) == bhalf && trow + k * 32 < a.bias_rows;
         if constexpr (k + 1 < KSTEPS) {
           step(SET{}, integral_constant<int, k + 1>{}, [&] {
-            // (the column-sum reads went out before step 0's: back by now)
-            if constexpr (k == 1) {
-              if (bias_tile) colsum_add(tile);
-            }
+            if (bsum) frag_colsum(SET{});
           });
         } else {
           // all but the DMAs of the tiles after i + 1 have landed (this wave's
@@ -602,9 +618,7 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
           // reads: step 0 of tile i + 1 (after the last tile: resident LDS
           // nobody uses); the DMA of tile i + NS goes into tile i's slot
           step(SET{}, integral_constant<int, 0>{}, [&] {
-            if constexpr (k == 1) {
-              if (bias_tile) colsum_add(tile);
-            }
+            if (bsum) frag_colsum(SET{});
             if (i + G::NS < n_i) issue_tile(soff);
           });
           soff += delta;
@@ -632,7 +646,7 @@ __device__ __forceinline__ void wgrad_ring_loop(const WgradArgs& a,
 template <int R, int TPW, bool ROWSPLIT, bool PIPE, int TT, int ALLT>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
                                            int bz, int gz, int tn,
-                                           int pslot CG_WTR_PARAMS) {
+                                           int pslot, int bias_cw CG_WTR_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(!ROWSPLIT || TT == 256, "row-split tiles are 256 rows");
   constexpr int NG = TT * 8 / 512;  // g pieces per thread (1, 2 or 4)
@@ -661,12 +675,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
 
   const int totalX = R * regionRows * 4;
   const int totalG = TT * 8;
-  const bool do_bias = a.dbias != nullptr && bx == 0;
+  // (bias_cw > 1, flex form: the members bx = 0 .. bias_cw - 1 of the team that
+  // holds cx block 0 share the tiles of the bias column sums)
+  const bool do_bias = a.dbias != nullptr && bx < bias_cw;
   float bs0 = 0.f, bs1 = 0.f;
 
   if constexpr (ALLT == 2) {
     static_assert(R == 2 && TPW == 3 && PIPE && !ROWSPLIT, "ring-staged form");
-    wgrad_ring_loop<TT>(a, smem, bx, by, bz, gz, tn, do_bias, acc, bs0, bs1 CG_WTR_ARGS);
+    wgrad_ring_loop<TT>(a, smem, bx, by, bz, gz, tn, do_bias, bias_cw, bx, acc, bs0,
+                        bs1 CG_WTR_ARGS);
     CG_WTR(wtr, wtt, 1);  // K' loop
   } else if (PIPE) {
     // per-thread piece coordinates (fixed across tiles)
@@ -810,14 +827,31 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, int bx, int by,
     // K' splits by the reducing launch) or one global atomic per channel
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
-    const int cp = (tid & 31) * 2;
-    red[(tid >> 5) * 64 + cp] = bs0;
-    red[(tid >> 5) * 64 + cp + 1] = bs1;
+    if constexpr (ALLT == 2) {
+      // ring form: one partial per lane (two chains) -- column (wave & 3) * 16 +
+      // (lane & 15), k-group lane >> 4 -- from the g fragments (wgrad_ring_loop)
+      red[tid] = bs0 + bs1;
+    } else {
+      const int cp = (tid & 31) * 2;
+      red[(tid >> 5) * 64 + cp] = bs0;
+      red[(tid >> 5) * 64 + cp + 1] = bs1;
+    }
     __syncthreads();
     if (tid < 64) {
-      float t = red[tid];
+      float t;
+      if constexpr (ALLT == 2) {
+        // the two waves of the column block, four k-groups each, in a fixed order
+        const int base = (tid >> 4) * 64 + (tid & 15);
+        t = red[base];
 #pragma unroll
-      for (int k = 1; k < 16; ++k) t += red[k * 64 + tid];
+        for (int k = 1; k < 4; ++k) t += red[base + k * 16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t += red[base + 256 + k * 16];
+      } else {
+        t = red[tid];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k * 64 + tid];
+      }
       if (a.bias_part)
         a.bias_part[(pslot >= 0 ? (long long)pslot : (long long)bz * a.pgy + by) * 64 +
                     tid] = t;
@@ -906,7 +940,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a, int gz) {
   unsigned wtr[kWTraceParts] = {};
   unsigned wtt = 0;
 #endif
-  wgrad_body<R, TPW, ROWSPLIT, PIPE, TT, ALLT>(a, bx, by, bz, gz, -1, -1 CG_WTR_ARGS);
+  wgrad_body<R, TPW, ROWSPLIT, PIPE, TT, ALLT>(a, bx, by, bz, gz, -1, -1, 1 CG_WTR_ARGS);
 }
 
 // Second stage of the partial-sum path: an element (block tile, slot, tid) is one
@@ -1061,9 +1095,9 @@ __global__ __launch_bounds__(512) void wgrad_multi_kernel(WgradMulti m) {
     if (mine && wgrad_block(m.a[li], m.zcnt[li], id, bx, by, bz)) {
       bz += m.zofs[li];
       if (m.tt[li] == 128)
-        wgrad_body<R, TPW, false, true, 128, ALLT>(m.a[li], bx, by, bz, gz, -1, -1 CG_WTR_ARGS);
+        wgrad_body<R, TPW, false, true, 128, ALLT>(m.a[li], bx, by, bz, gz, -1, -1, 1 CG_WTR_ARGS);
       else
-        wgrad_body<R, TPW, false, true, 64, ALLT>(m.a[li], bx, by, bz, gz, -1, -1 CG_WTR_ARGS);
+        wgrad_body<R, TPW, false, true, 64, ALLT>(m.a[li], bx, by, bz, gz, -1, -1, 1 CG_WTR_ARGS);
     }
     CG_WTR(wtr, wtt, 3);  // (items this workgroup has no share of; flush of atomics forms)
     __syncthreads();  // LDS is reused by the next item
@@ -1099,6 +1133,7 @@ constexpr int kFlexItemInts = 6;  // layer (< 0: end), bx, by, first K' tile, ti
 struct WgradFlex {
   int n;
   int tt[kMaxBatch];
+  int cw[kMaxBatch];  // live cx blocks (power of two) of the team that holds cx block 0
   const int* table;  // [workgroups][kFlexMaxItems][kFlexItemInts]
   WgradArgs a[kMaxBatch];
 };
@@ -1124,9 +1159,9 @@ __global__ __launch_bounds__(512) void wgrad_flex_kernel(WgradFlex m) {
     const int kn = __builtin_amdgcn_readfirstlane(it[4]);
     const int ps = __builtin_amdgcn_readfirstlane(it[5]);
     if (m.tt[li] == 128)
-      wgrad_body<R, TPW, false, true, 128, ALLT>(m.a[li], bx, by, k0, 1, kn, ps CG_WTR_ARGS);
+      wgrad_body<R, TPW, false, true, 128, ALLT>(m.a[li], bx, by, k0, 1, kn, ps, m.cw[li] CG_WTR_ARGS);
     else
-      wgrad_body<R, TPW, false, true, 64, ALLT>(m.a[li], bx, by, k0, 1, kn, ps CG_WTR_ARGS);
+      wgrad_body<R, TPW, false, true, 64, ALLT>(m.a[li], bx, by, k0, 1, kn, ps, m.cw[li] CG_WTR_ARGS);
     CG_WTR(wtr, wtt, 3);
     __syncthreads();  // LDS is reused by the next item
     CG_WTR(wtr, wtt, 4);
@@ -1146,6 +1181,7 @@ struct FlexReduceItem {
   const int* tiles;        // [gx * gy][2] in device memory
   int gx, gy, tpw, taps, Cx_real, Cg_real;
   int store, zc;
+  int cw;                  // tiles (0 .. cw - 1, cg block) hold shares of the bias sums
   const float* bias_part;  // [slot][64] or null
   float* dbias;
 };
@@ -1161,10 +1197,12 @@ __global__ __launch_bounds__(256) void wgrad_flex_reduce_kernel(FlexReduceArgs r
     // conv bias gradient: column sums of the (cx block 0, cg block) tiles' items,
     // in slot (= ascending K') order
     for (int c = threadIdx.x; c < it.gy * 64; c += 256) {
-      const int t = (c >> 6) * it.gx;
-      const int p0 = it.tiles[2 * t], cnt = it.tiles[2 * t + 1];
       float s = 0.f;
-      for (int z = 0; z < cnt; ++z) s += it.bias_part[(long long)(p0 + z) * 64 + (c & 63)];
+      for (int bx = 0; bx < it.cw; ++bx) {  // (the team members' tile shares, in order)
+        const int t = (c >> 6) * it.gx + bx;
+        const int p0 = it.tiles[2 * t], cnt = it.tiles[2 * t + 1];
+        for (int z = 0; z < cnt; ++z) s += it.bias_part[(long long)(p0 + z) * 64 + (c & 63)];
+      }
       if (c < it.Cg_real) {
         if (it.store) it.dbias[c] = s;
         else it.dbias[c] += s;
@@ -1346,7 +1384,9 @@ int plan_wgrad(const cg_wgrad_desc* d, WgradPlan& p) {
   p.ring_lds = 0;
   if (!rowsplit && p.pipe && d->taps == 24 && !d->classic_staging &&
       (long long)d->Lx * d->Cx * 2 < (1ll << 31) &&
-      (!d->shifts || (d->nB + d->seg_size - 1) / d->seg_size <= 64)) {
+      (!d->shifts || (d->nB + d->seg_size - 1) / d->seg_size <= 64) &&
+      // (the ring form sums the bias columns per 32-row K-step)
+      (!d->dbias || d->bias_rows % 32 == 0)) {
     a.ring = 1;
     p.ring_lds = TT == 128 ? 4 * RingGeom<128>::STAGE : 4 * RingGeom<64>::STAGE;
   }
@@ -1662,6 +1702,7 @@ struct FlexPlan {
   int nslots[kMaxBatch] = {};
   int tile_ofs[kMaxBatch] = {};  // ints from the start of the table
   int zc[kMaxBatch] = {};
+  int cw[kMaxBatch] = {};        // members that share the bias column sums of a layer
   int nitems = 0;                // (team, column) pairs x live members
 };
 
@@ -1783,6 +1824,16 @@ void plan_flex(const WgradPlan* plans, int n, int mode, FlexPlan& fp) {
   }
   const int nwg = (nteams + 7) / 8 * 8 * S;
   fp.S = S; fp.nteams = nteams; fp.nwg = nwg;
+  // members that share the bias column sums: the largest power of two of LIVE cx
+  // blocks in the column of cx block 0 (they stream the same g tiles)
+  for (int i = 0; i < n; ++i) fp.cw[i] = 1;
+  for (const FlexCol& c : cols) {
+    if (c.bx0 != 0) continue;
+    const int live = c.cw < plans[c.layer].gx ? c.cw : plans[c.layer].gx;
+    int b = 1;
+    while (b * 2 <= live) b *= 2;
+    fp.cw[c.layer] = b;
+  }
   const size_t items_ints = (size_t)nwg * kFlexMaxItems * kFlexItemInts;
   size_t tiles_ints = 0;
   for (int i = 0; i < n; ++i) {
@@ -1943,8 +1994,10 @@ int run_flex(const cg_wgrad_desc* descs, int n, WgradPlan* plans, hipStream_t s)
     m.a[i].bias_part = bias ? descs[i].partials + dw_part : nullptr;
     m.a[i].direct_store = 0;
     m.tt[i] = p.TT;
+    m.cw[i] = fp->cw[i];
     if (2 * p.lds > lds) lds = 2 * p.lds;
     FlexReduceItem& it = ra.it[i];
+    it.cw = fp->cw[i];
     it.part = m.a[i].part; it.dw = p.a.dw;
     it.tiles = fp->dev + fp->tile_ofs[i];
     it.gx = p.gx; it.gy = p.gy; it.tpw = p.tpw; it.taps = p.a.taps;

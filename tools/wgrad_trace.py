@@ -94,5 +94,29 @@ def per_layer(gan, t):
               kloop[sel].mean() / np.mean(tiles), int(np.mean(tiles))))
 
 
+  # the workgroups of cx block 0 also sum the bias columns of their g tiles
+  b0 = [w for w in range(min(nwg, 256)) if any(r[0] >= 0 and r[1] == 0 for r in items[w])]
+  bn = [w for w in range(min(nwg, 256)) if any(r[0] >= 0 for r in items[w]) and w not in b0]
+  print('    workgroups with a cx-block-0 item (bias column sums): %d, life %.0f k; the others: %d, '
+        'life %.0f k' % (len(b0), life[b0].mean() / 1e3, len(bn), life[bn].mean() / 1e3))
+  # leader effect: life by the workgroup's position in its team (slot (id >> 3) % S),
+  # all workgroups / only those without a cx-block-0 item
+  S = info[0]
+  pos = (np.arange(min(nwg, 256)) >> 3) % S
+  print('    life by team position (k cycles), all:', ' '.join(
+      '%4.0f' % (life[:len(pos)][pos == m].mean() / 1e3) for m in range(S)),
+        '| without bias sums:', ' '.join(
+            '%4.0f' % (np.mean([life[w] for w in bn if pos[w] == m] or [0]) / 1e3)
+            for m in range(S)))
+  # who is slow: by XCD (id & 7), and the eight longest-lived workgroups
+  ids = np.arange(min(nwg, 256))
+  print('    life by XCD (k cycles):', ' '.join(
+      '%4.0f' % (life[ids[(ids & 7) == x]].mean() / 1e3) for x in range(8)))
+  for w in np.argsort(-life[:min(nwg, 256)])[:8]:
+    its = [tuple(int(v) for v in r) for r in items[w] if r[0] >= 0]
+    print('    slowest: wg %3d (xcd %d) life %4.0f k  items (layer, bx, by, k0, kn, slot) %s' % (
+        w, w & 7, life[w] / 1e3, its))
+
+
 if __name__ == '__main__':
   main()
