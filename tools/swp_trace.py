@@ -95,6 +95,24 @@ def main():
       line += '   %6.0f per tile' % (per / tiles_per_wg)
     print(line)
   print('  (16 MFMAs per stage and wave = 256 matrix-pipe cycles; x waves per SIMD)')
+  # who ends the launch (round 5): life per WORKGROUP (mean of its waves), by XCD,
+  # by resident slot of the CU (ids 256 apart share a CU) and by start phase
+  nwg = int(live.any(1).sum())
+  wl = np.array([t[i][live[i]][:, :10].sum(-1).mean() for i in range(nwg)])
+  ids = np.arange(nwg)
+  print('  workgroup life: mean %.0f k, min %.0f k, max %.0f k (max / mean %.3f)' % (
+      wl.mean() / 1e3, wl.min() / 1e3, wl.max() / 1e3, wl.max() / wl.mean()))
+  print('    by XCD (id & 7):      ', ' '.join('%4.0f' % (wl[(ids & 7) == x].mean() / 1e3)
+                                               for x in range(8)))
+  print('    by CU slot (id >> 8): ', ' '.join('%4.0f' % (wl[(ids >> 8) == x].mean() / 1e3)
+                                               for x in range((nwg + 255) // 256)))
+  print('    by id bit 0:          ', ' '.join('%4.0f' % (wl[(ids & 1) == x].mean() / 1e3)
+                                               for x in range(2)))
+  print('    by 32-id block:       ', ' '.join('%4.0f' % (wl[i:i + 32].mean() / 1e3)
+                                               for i in range(0, nwg, 32)))
+  k_loop = np.array([t[i][live[i]][:, :5].sum(-1).mean() for i in range(nwg)])
+  print('    K loop part only:      mean %.0f k, min %.0f k, max %.0f k' % (
+      k_loop.mean() / 1e3, k_loop.min() / 1e3, k_loop.max() / 1e3))
 
 
 if __name__ == '__main__':
