@@ -40,9 +40,12 @@ def make_hparams(L, C, U, m, mixed_precision=False):
       algorithm='wgan-gp', verbose=0)
 
 
-def algorithmic_flops(hp):
+def algorithmic_flops(hp, l1_mix=False):
   """FLOPs per training sample of one train(): 8 F_G + 52 F_D - 10 F_D1
-  (SURVEY 3.3 / BASELINE.md 2), split by kernel family."""
+  (SURVEY 3.3 / BASELINE.md 2), split by kernel family.  l1_mix (round 5): the
+  critic's first layer on x^ comes from the layer's outputs on real and fake
+  (cg_lrelu_mix) -- n F_D1 that the step does NOT execute leave the cg_swconv
+  family's count (a rate is credited only with work done)."""
   from calciumgan_amd import geometry as geo
   k = hp.kernel_size
   g_layers, d_layers = geo.generator_layers(hp), geo.discriminator_layers(hp)
@@ -65,15 +68,17 @@ def algorithmic_flops(hp):
   dense_fwd_bwd = ((n + 1) + (1 if cp >= 128 else 0)) * f_dense if streaming else 0.0
   # its weight gradient always runs in cg_dense_wgrad (not a cg_wgrad launch)
   dense_rows = dense_fwd_bwd + f_dense
-  swconv = n * (f_g + 7 * f_d - 2 * f_d1) + 2 * f_g + 2 * f_d - dense_fwd_bwd
+  skipped = n * f_d1 if l1_mix else 0.0
+  swconv = (n * (f_g + 7 * f_d - 2 * f_d1) + 2 * f_g + 2 * f_d - dense_fwd_bwd -
+            skipped)
   wgrad = n * 3 * f_d + f_g - f_dense
-  total = (n + 3) * f_g + (10 * n + 2) * f_d - 2 * n * f_d1
+  total = (n + 3) * f_g + (10 * n + 2) * f_d - 2 * n * f_d1 - skipped
   assert abs(total - swconv - wgrad - dense_rows) < 1e-3 * total
   return dict(total=total, swconv=swconv, wgrad=wgrad, f_g=f_g, f_d=f_d,
               dense_rows=dense_rows)
 
 
-def algorithmic_bytes_swconv(hp, B, batched_g=False):
+def algorithmic_bytes_swconv(hp, B, batched_g=False, l1_mix=False):
   """Algorithmic HBM bytes of all cg_swconv launches of one train(): every
   launch reads its bf16 source tensor and its packed bf16 weights once and
   writes its output once (bf16; f32 for the generator output).  batched_g:
@@ -132,6 +137,8 @@ def algorithmic_bytes_swconv(hp, B, batched_g=False):
   # with their sign: every launch also READS the bf16 activation it overwrites --
   # counted since round 5, as tools/traffic_by_geometry.py does per launch)
   critic += sum(B * l.lout * l.coutp * 2 for l in d_l)
+  if l1_mix:  # layer 1 forward runs over [real | fake] only
+    critic -= B * (d_l[0].lin * d_l[0].cinp * 2 + d_l[0].lout * d_l[0].coutp * 2)
   gen = g_forward(True) + d_fwd(B) + sum(dgrad(B, l, masked=fusable(l))
                                for l in d_l[1:]) + \
       dgrad(B, d_l[0]) + g_bwd
@@ -303,7 +310,8 @@ def main():
                                        args.m, B) == (2048, 102, 64, 10, 128) else
       'custom shapes (not a BASELINE.json config)')
   if rank == 0:
-    fl = algorithmic_flops(hp)
+    l1_mix = bool(gan._get_state(B)['critic'].mixes_layer1)
+    fl = algorithmic_flops(hp, l1_mix=l1_mix)
     value = world * B * args.steps / dt
     roofline = None
     fam = {}
@@ -330,7 +338,8 @@ def main():
               args.steps, dt_prof / args.steps * 1e3, dt / args.steps * 1e3))
       from calciumgan_amd.gan.algorithms import wgan_gp as _w
       ab, alaunch = algorithmic_bytes_swconv(
-          hp, B, batched_g=world == 1 and _w._BATCH_G and not _w._FORCE_SPLIT)
+          hp, B, batched_g=world == 1 and _w._BATCH_G and not _w._FORCE_SPLIT,
+          l1_mix=l1_mix)
       roofline['algorithmic_hbm_bytes_per_launch'] = ab / alaunch
       # context, not the roofline's denominator: what dense bf16 MFMA SUSTAINS on
       # random operands under the package power cap (tools/probe/mfma_sustained.hip,
@@ -385,6 +394,11 @@ def main():
             'parallelism': 'dp{}'.format(world),
             'launch': 'hipGraph replay of train()' if getattr(
                 gan, '_use_graph', False) else 'eager launches',
+            # (round 5; CALCIUMGAN_L1_LINEAR=0 convolves x^ like the other segments;
+            # FLOP counts below are of the work executed either way)
+            'critic_layer1_on_interpolate':
+                'a*y_real + (1-a)*y_fake from the stored outputs (cg_lrelu_mix)'
+                if l1_mix else 'convolved',
         },
         'gflop_per_sample_step': fl['total'] / 1e9,
         'model_tflops': value * fl['total'] / 1e12,

@@ -168,6 +168,7 @@ SIGNATURES = {
     'cg_colsum': [c_vp, c_vp, c_ll, c_i, c_i, c_vp, c_vp],
     'cg_sigmoid_bwd': [c_vp, c_vp, c_vp, c_ll, c_i, c_i, c_i, c_vp],
     'cg_lrelu_bwd': [c_vp, c_vp, c_vp, c_ll, c_f, c_vp],
+    'cg_lrelu_mix': [c_vp, c_vp, c_vp, c_vp, c_i, c_ll, c_f, c_vp],
     'cg_adam': [c_vp, c_vp, c_vp, c_vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_vp,
                 c_vp],
     'cg_grad_finite': [c_vp, c_ll, c_vp, c_vp],

@@ -228,7 +228,9 @@ __global__ __launch_bounds__(kDrThreads, 2) void dense_rows_interp_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int b = (int)((blk * 16) / a.L);  // the block's sample
-    const float al = a.alpha[k * a.B + b];
+    // (alpha == nullptr: the caller forms layer 1 on x^ from the layer's outputs on
+    // real and fake, cg_lrelu_mix -- x^ itself is never read, so never written)
+    const float al = a.alpha ? a.alpha[k * a.B + b] : 0.f;
     uint16_t* x0 = a.x0[k];
 #pragma unroll 2
     for (int pass = 0; pass < 8; ++pass) {
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(kDrThreads, 2) void dense_rows_interp_kernel(
         uint16_t* q = x0 + m * a.Cp + tcol;
         store4(q, rr[pass]);
         store4(q + seg, f);
-        store4(q + 2 * seg, xh);
+        if (a.alpha) store4(q + 2 * seg, xh);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -709,13 +711,14 @@ extern "C" int cg_dense_rows(const void* x, const void* w, const float* bias,
 }
 
 // cg_dense_rows for the fake batches of all n critic updates of a step, fused
-// with cg_interp_pack: x0[k] (bf16 [3 B][L][Cp]) receives [real | fake_k | x^_k].
+// with cg_interp_pack: x0[k] (bf16 [3 B][L][Cp]) receives [real | fake_k | x^_k]
+// (alpha == NULL: [real | fake_k | untouched]).
 extern "C" int cg_dense_rows_interp(const void* x, const void* w, const float* bias,
                                     const float* real, const float* alpha,
                                     void* const* x0, int n, int B, int L, int Cx,
                                     int N, int Cr, int Cp, int epilogue,
                                     void* stream) {
-  if (!x || !w || !real || !alpha || !x0 || n < 1 || n > kMaxInterp || B < 1 || L < 16 ||
+  if (!x || !w || !real || !x0 || n < 1 || n > kMaxInterp || B < 1 || L < 16 ||
       L % 16)
     return CG_EINVAL;
   if (epilogue != CG_EPI_NONE && epilogue != CG_EPI_SIGMOID) return CG_EINVAL;

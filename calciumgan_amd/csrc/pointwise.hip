@@ -1191,6 +1191,31 @@ __global__ __launch_bounds__(kThreads) void lrelu_bwd_kernel(
   store8(dpre + idx * 8, a);
 }
 
+// Layer 1 of the critic on x^ = a real + (1 - a) fake without the convolution
+// (wgan_gp.py:41-47, 68-72; round 5): a convolution is linear, so the layer's
+// pre-activation on x^ is a y_real + (1 - a) y_fake (the bias rides along, a +
+// (1 - a) = 1).  h = max(y, alpha y) with 0 < alpha <= 1 is inverted exactly up to
+// the rounding of the stored activation: y = h > 0 ? h : h / alpha.
+__global__ __launch_bounds__(kThreads) void lrelu_mix_kernel(
+    const uint16_t* __restrict__ ha, const uint16_t* __restrict__ hb,
+    const float* __restrict__ mix, uint16_t* __restrict__ out,
+    long long per_sample8, long long total8, float alpha, float inv_alpha) {
+  const long long idx = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= total8) return;
+  const float al = mix[idx / per_sample8];
+  float a[8], b[8];
+  load8(ha + idx * 8, a);
+  load8(hb + idx * 8, b);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float ya = a[e] > 0.f ? a[e] : a[e] * inv_alpha;
+    const float yb = b[e] > 0.f ? b[e] : b[e] * inv_alpha;
+    const float y = al * ya + (1.f - al) * yb;
+    a[e] = fmaxf(y, alpha * y);
+  }
+  store8(out + idx * 8, a);
+}
+
 __global__ __launch_bounds__(kThreads) void adam_kernel(
     float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m,
     float* __restrict__ v, long long n, float lr_t, float b1, float b2,
@@ -1947,6 +1972,17 @@ extern "C" int cg_lrelu_bwd(const void* dh, const void* h, void* dpre,
   hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid1d(total8, kThreads, 1LL << 31)),
                      dim3(kThreads), 0, S_(stream), U16(dh), U16(h), U16W(dpre),
                      alpha, total8);
+  CG_LAUNCH_CHECK();
+}
+
+extern "C" int cg_lrelu_mix(const void* h_a, const void* h_b, const float* mix,
+                            void* out, int B, long long n_per_sample, float alpha,
+                            void* stream) {
+  if (n_per_sample % 8 || B < 1 || !(alpha > 0.f && alpha <= 1.f)) return CG_EINVAL;
+  const long long per8 = n_per_sample / 8, total8 = per8 * B;
+  hipLaunchKernelGGL(lrelu_mix_kernel, dim3(grid1d(total8, kThreads, 1LL << 31)),
+                     dim3(kThreads), 0, S_(stream), U16(h_a), U16(h_b), mix,
+                     U16W(out), per8, total8, alpha, 1.f / alpha);
   CG_LAUNCH_CHECK();
 }
 

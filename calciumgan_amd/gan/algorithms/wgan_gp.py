@@ -211,7 +211,8 @@ class WGAN_GP(GAN):
       _lib.call('cg_interp_pack', nets._p(real), nets._p(fake), nets._p(alpha),
                 nets._p(plan.x0), B, lay.lin, lay.cin, lay.cin,
                 self.generator.net.Cf, lay.cinp, 0 if real_cached else 1, s)
-    plan.forward(seed_backward=True)
+    plan.forward(seed_backward=True,
+                 mix=alpha.reshape(-1) if plan.mixes_layer1 else None)
     plan.backward_chain(seeded=True)
     n = lay.lin * lay.cinp
     if plan.norm_deferred:
@@ -270,8 +271,10 @@ class WGAN_GP(GAN):
     ws = self.generator.net.workspace(n * B, forward_only=True)
     if alphas is not None:
       st = self._get_state(B)
+      # (plans that form layer 1 of x^ from the other two segments' never read x^)
       ws.forward(z, keep=False,
-                 interp=(real, alphas, [st['dws'].x0(k) for k in range(n)]))
+                 interp=(real, None if st['critic'].mixes_layer1 else alphas,
+                         [st['dws'].x0(k) for k in range(n)]))
       return [None] * n
     fake = ws.forward(z, keep=False)
     return [fake[i * B:(i + 1) * B] for i in range(n)]
@@ -423,7 +426,10 @@ class WGAN_GP(GAN):
           z = self.get_noise(B) if drawn else self._to_device(r['z'])
           a = (self._streams.alpha(B) if drawn
                else self._to_device(r['alpha']).reshape(-1))
-          st['gws'].forward(z, keep=False, interp=(real, a, [st['dws'].x0(0)]))
+          st['gws'].forward(
+              z, keep=False,
+              interp=(real, None if st['critic'].mixes_layer1 else a,
+                      [st['dws'].x0(0)]))
           box[key] = None
           box[('alpha', key)] = a
           box[('packed', key)] = True

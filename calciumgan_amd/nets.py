@@ -351,6 +351,15 @@ def _conv_desc(x, w, y, nB, Lx, Cx, taps, stride, off, Lu, N, Ly, Cy, CK,
 # (cg_scale_rows into X0) instead of a per-sample scale in the tangent chain's
 # first launch + a pass over the x^ segment of delta_1
 _FOLD_SCALE = __import__('os').environ.get('CALCIUMGAN_FOLD_SCALE', '1') != '0'
+# Critic layer 1 on x^ = a real + (1 - a) fake taken from the layer's outputs on
+# real and fake (the convolution is linear: cg_lrelu_mix) instead of a third of the
+# layer's launch; x^ itself is then never formed.  0: convolve x^ like the other two
+# segments (rounds 1-4).
+_L1_LINEAR = __import__('os').environ.get('CALCIUMGAN_L1_LINEAR', '1') != '0'
+# ... for segments of at least this many layer-1 output rows (B * L / 2): below,
+# a third of the layer's launch is shorter than the extra launch (cfg2: 131 072)
+_L1_LINEAR_MIN_ROWS = int(__import__('os').environ.get(
+    'CALCIUMGAN_L1_LINEAR_MIN_ROWS', '16384'))
 # Split-K candidates of the tile tuner (CALCIUMGAN_SPLIT_K=0: never): only for
 # launches whose output is at most this many 64x64 tiles
 _SPLIT_K = __import__('os').environ.get('CALCIUMGAN_SPLIT_K', '1') != '0'
@@ -891,6 +900,18 @@ class _DisPlan(object):
                                     off_phase_step=net.dgrad_offs[1] -
                                     net.dgrad_offs[0], yoff_phase_step=1,
                                     **extra)))
+    # layer 1 over [real | fake] only + cg_lrelu_mix for the x^ segment (_L1_LINEAR)
+    self.fwd_l1_pair = None
+    if (_L1_LINEAR and self.nseg == 3 and nB == 3 * seg_size and
+        input_grad_from == 2 * seg_size and 0.0 < net.alpha <= 1.0 and
+        seg_size * net.layers[0].lout >= _L1_LINEAR_MIN_ROWS):
+      lay, op = net.layers[0], net.w_fwd[0]
+      self.fwd_l1_pair = _conv_desc(
+          self.x0[:2 * seg_size], op.buf, ws.act[1][:2 * seg_size], 2 * seg_size,
+          lay.lin, lay.cinp, k, 2, -pl, lay.lout, lay.cout, lay.lout, lay.coutp,
+          op.CK, bias=net.params.views[1], seg_size=seg_size,
+          epilogue=_lib.EPI_LRELU, w_parity_major=op.parity_major,
+          w_narrow_last=op.narrow_last, alpha=net.alpha)
     self.input_grad = None
     self.gin = None
     if input_grad_from is not None:
@@ -973,14 +994,31 @@ class _DisPlan(object):
       self.jvp = build(False)
 
   # -- schedules ------------------------------------------------------------
-  def forward(self, seed_backward=False):
+  @property
+  def mixes_layer1(self):
+    """forward(mix=alpha) forms layer 1 of the x^ segment from the real and fake
+    segments' (the plan's X0 need not hold x^ then)."""
+    return self.fwd_l1_pair is not None
+
+  def forward(self, seed_backward=False, mix=None):
     """act[0] (already filled) -> d_out[:nB].  seed_backward: the head's pass
     over h5 also writes delta_5 = coef * w_d * lrelu'(h5) (the seed does not
     depend on the head's output: one launch and one read of h5 instead of two);
-    backward_chain(seeded=True) then starts from it."""
+    backward_chain(seeded=True) then starts from it.  mix (f32 per sample of a
+    segment; plans with mixes_layer1): the third segment is x^ = mix * real +
+    (1 - mix) * fake -- its layer 1 is cg_lrelu_mix of the first two segments'."""
     st = _stream()
     net, ws = self.ws.net, self.ws
-    for d in self.fwd:
+    if mix is not None and self.fwd_l1_pair is not None:
+      B, lay = self.seg_size, net.layers[0]
+      a1 = ws.act[1]
+      _run_conv(self.fwd_l1_pair, st)
+      _lib.call('cg_lrelu_mix', _p(a1[:B]), _p(a1[B:2 * B]), _p(mix),
+                _p(a1[2 * B:3 * B]), B, lay.lout * lay.coutp, net.alpha, st)
+      rest = self.fwd[1:]
+    else:
+      rest = self.fwd
+    for d in rest:
       _run_conv(d, st)
     last = net.layers[-1]
     if seed_backward:

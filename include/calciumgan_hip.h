@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define CG_EINVAL 100001
-#define CG_ABI_VERSION 18
+#define CG_ABI_VERSION 19
 
 /* epilogue selectors of cg_swconv */
 #define CG_EPI_NONE 0     /* y = acc (+bias) */
@@ -239,7 +239,9 @@ int cg_dense_rows(const void* x, const void* w, const float* bias, float* y,
  * alpha[k * B + b] * real + (1 - alpha) * fake (wgan_gp.py:38-41, interpolation
  * in f32 on the f32 Dense output as the reference does).  The f32 fake batch
  * never reaches HBM and `real` (f32 [B][L][Cr]) is read once.  L % 16 == 0,
- * n <= 8.  The bytes of x0[k] equal those of cg_dense_rows + cg_interp_pack. */
+ * n <= 8.  The bytes of x0[k] equal those of cg_dense_rows + cg_interp_pack.
+ * alpha == NULL (ABI 19): the x^ segment is left untouched -- the caller forms the
+ * critic's first layer on x^ with cg_lrelu_mix and never reads x^ itself. */
 int cg_dense_rows_interp(const void* x, const void* w, const float* bias,
                          const float* real, const float* alpha, void* const* x0,
                          int n, int B, int L, int Cx, int N, int Cr, int Cp,
@@ -528,6 +530,13 @@ int cg_sigmoid_bwd(const void* dfake /*bf16 [rows][Cp]*/,
 /* dpre = dh * lrelu'(h), all bf16 [n] */
 int cg_lrelu_bwd(const void* dh, const void* h, void* dpre, long long n,
                  float alpha, void* stream);
+/* out[b] = act(mix[b] * act^-1(h_a[b]) + (1 - mix[b]) * act^-1(h_b[b])), all bf16
+ * [B][n_per_sample], act(y) = max(y, alpha y) with 0 < alpha <= 1: the critic's first
+ * layer on x^ = a real + (1 - a) fake (gan/algorithms/wgan_gp.py:41-47 feeding
+ * gan/models/calciumgan.py:159-166) from that layer's outputs on real and fake -- the
+ * convolution is linear, so the x^ segment needs no convolution of its own. */
+int cg_lrelu_mix(const void* h_a, const void* h_b, const float* mix, void* out,
+                 int B, long long n_per_sample, float alpha, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Keras Adam (gan/algorithms/optimizer.py:9; tf.keras.optimizers.Adam):

@@ -30,7 +30,7 @@ __all__ = [
     'phase_shuffle_index', 'init_generator', 'init_discriminator',
     'count_params', 'generator_nontrainable', 'BN_EPS', 'BN_MOMENTUM',
     'generator_forward', 'discriminator_forward',
-    'interpolation', 'gradient_penalty', 'discriminator_loss',
+    'interpolation', 'gradient_penalty', 'layer1_mix_pre', 'discriminator_loss',
     'generator_loss', 'd_step_grads', 'g_step_grads', 'keras_adam',
     'signal_metrics', 'draw_randomness', 'OracleGAN', 'bf16_round',
     'f16_round', 'DynamicLossScale',
@@ -163,6 +163,12 @@ class DynamicLossScale(object):
       self.scale = max(self.scale / self.multiplier, 1.0)
       self.good_steps = 0
     return finite
+
+
+def _is_rounding(q):
+  """Whether q is one of the storage-point emulations (tests pass `lambda x: x`
+  for the f32 oracle as well as the default _ident)."""
+  return q in (bf16_round, f16_round)
 
 
 def _ident(x):
@@ -405,16 +411,21 @@ def generator_forward(weights, z, hp, q=_ident, wq=_ident, training=True,
   return x
 
 
-def discriminator_forward(weights, x, shifts, hp, q=_ident, wq=_ident):
+def discriminator_forward(weights, x, shifts, hp, q=_ident, wq=_ident, pre1=None):
   """discriminator -- calciumgan.py:141-192.  x (B, L, C) -> (B, 1).
-  shifts: 4 ints, the PhaseShuffle draws after layers 1-4 of THIS call."""
+  shifts: 4 ints, the PhaseShuffle draws after layers 1-4 of THIS call.
+  pre1 (storage-point emulation only, see layer1_mix_pre): VALUES of the first
+  layer's pre-activation; derivatives stay those of the convolution."""
   assert len(shifts) == NUM_CONVS - 1
   it = iter(weights)
   act = activation_fn(getattr(hp, 'activation', 'leakyrelu'))
   x = q(x)
   for layer in range(NUM_CONVS):
     cw, cb = next(it), next(it)
-    x = q(act(conv1d_same(x, wq(cw), cb, hp.strides)))
+    y = conv1d_same(x, wq(cw), cb, hp.strides)
+    if layer == 0 and pre1 is not None:
+      y = y + (pre1 - y).detach()
+    x = q(act(y))
     if layer < NUM_CONVS - 1:
       x = phase_shuffle(x, shifts[layer])
   dw, db = next(it), next(it)
@@ -436,13 +447,44 @@ def interpolation(real, fake, alpha):
   return a * real + (1 - a) * fake
 
 
+# The emulation of the HIP path's storage points (q != identity) follows where that
+# path rounds, not what the reference computes.  Since round 5 the HIP path forms
+# the critic's first layer on x^ from the layer's STORED outputs on real and fake
+# at large batches (a convolution is linear; calciumgan_amd.nets._L1_LINEAR); set
+# this flag and the emulation takes the same values there (tools/probe/
+# critic_noise.py, tests of that form).  The f32 oracle (q = identity: the
+# restatement of the reference every parity bar is stated against) never does.
+EMULATE_LAYER1_MIX = False
+
+
+def layer1_mix_pre(dis_weights, real, fake, alpha, hp, q, wq):
+  """Pre-activation of the critic's first Conv1D on x^ = a real + (1 - a) fake as
+  the HIP path forms it: a y_real + (1 - a) y_fake with y = act^-1 of the stored
+  (q-rounded) activations.  None when the activation has no such inverse."""
+  name = getattr(hp, 'activation', 'leakyrelu')
+  if name not in ('leakyrelu', 'linear'):
+    return None
+  slope = LEAKY_ALPHA if name == 'leakyrelu' else 1.0
+  act = activation_fn(name)
+  with torch.no_grad():
+    cw, cb = wq(dis_weights[0].detach()), dis_weights[1].detach()
+    hr = q(act(conv1d_same(q(real.detach()), cw, cb, hp.strides)))
+    hf = q(act(conv1d_same(q(fake.detach()), cw, cb, hp.strides)))
+    inv = lambda h: torch.where(h > 0, h, h * (1.0 / slope))
+    a = alpha.reshape(-1, 1, 1)
+    return a * inv(hr) + (1 - a) * inv(hf)
+
+
 def gradient_penalty(dis_weights, real, fake, alpha, shifts, hp, q=_ident,
                      wq=_ident, create_graph=True):
   """wgan_gp.py:43-50.  Returns (gp, per-sample norms, gradient)."""
   inter = interpolation(real, fake, alpha)
   if not inter.requires_grad:
     inter = inter.detach().requires_grad_(True)
-  out = discriminator_forward(dis_weights, inter, shifts, hp, q, wq)
+  pre1 = None
+  if EMULATE_LAYER1_MIX and q is not _ident and _is_rounding(q):
+    pre1 = layer1_mix_pre(dis_weights, real, fake, alpha, hp, q, wq)
+  out = discriminator_forward(dis_weights, inter, shifts, hp, q, wq, pre1=pre1)
   grad, = torch.autograd.grad(out.sum(), inter, create_graph=create_graph)
   norm = grad.reshape(grad.shape[0], -1).pow(2).sum(dim=1).sqrt()  # tf.norm
   return ((norm - 1.0)**2).mean(), norm, grad

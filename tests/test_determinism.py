@@ -70,7 +70,7 @@ def test_atomics_form_is_still_available_and_close():
     # round 5
     'CALCIUMGAN_WGRAD_FLEX=0', 'CALCIUMGAN_SWP_CHUNK_INNER=0',
     'CALCIUMGAN_FUSE_INTERP=0', 'CALCIUMGAN_LN_POW2=1', 'CALCIUMGAN_AUTOTUNE=1',
-    'CALCIUMGAN_DEFER_FINISH=0'])
+    'CALCIUMGAN_DEFER_FINISH=0', 'CALCIUMGAN_L1_LINEAR=0'])
 def test_every_documented_switch_is_a_working_configuration(knob):
   """README's switches select older / alternative forms of the same arithmetic.
   Each must still train: the first train() call (five critic updates + one

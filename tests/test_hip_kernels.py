@@ -1078,6 +1078,48 @@ def test_discriminator_head_kernels():
     np.testing.assert_allclose(db.cpu().numpy(), [0.0], atol=1e-6)
 
 
+@pytest.mark.parametrize('slope', [0.25, 0.2, 1.0])
+def test_lrelu_mix_inverts_the_activation_and_interpolates(slope):
+  """cg_lrelu_mix: out = act(a act^-1(h_a) + (1 - a) act^-1(h_b)), act(y) = max(y,
+  slope y) -- the critic's first layer on x^ from its outputs on real and fake
+  (round 5).  Exact where the arithmetic is (slope 1/4, mixing factors in {0, 1/4,
+  1/2, 1}, small integers); within one bf16 ulp of the f64 formula on random data;
+  slopes outside (0, 1] are refused (the activation is then not invertible / not
+  increasing on both branches)."""
+  rng = np.random.RandomState(23)
+  B, n = 5, 64 * 40
+  if slope == 0.25:
+    ya = rng.randint(-32, 33, (B, n)).astype(np.float32) * 4
+    yb = rng.randint(-32, 33, (B, n)).astype(np.float32) * 4
+    mix = np.array([0.0, 0.25, 0.5, 1.0, 0.75], np.float32)
+  else:
+    ya = rng.randn(B, n).astype(np.float32)
+    yb = rng.randn(B, n).astype(np.float32)
+    mix = rng.rand(B).astype(np.float32)
+  act = lambda y: np.maximum(y, slope * y)
+  ha = torch.tensor(act(ya)).to(BF16)
+  hb = torch.tensor(act(yb)).to(BF16)
+  out = torch.zeros(B, n, dtype=BF16, device=H.DEV)
+  ha_d, hb_d, mix_d = ha.to(H.DEV), hb.to(H.DEV), torch.tensor(mix).to(H.DEV)
+  _lib.call('cg_lrelu_mix', H.p(ha_d), H.p(hb_d), H.p(mix_d), H.p(out), B, n,
+            slope, H.stream())
+  H.sync()
+  inv = lambda h: np.where(h > 0, h, h / slope)
+  pa, pb = inv(ha.float().numpy().astype(np.float64)), inv(hb.float().numpy().astype(np.float64))
+  want = act(mix[:, None].astype(np.float64) * pa + (1 - mix[:, None].astype(np.float64)) * pb)
+  got = out.float().cpu().numpy()
+  if slope == 0.25:
+    np.testing.assert_array_equal(got, want.astype(np.float32))
+  else:
+    np.testing.assert_allclose(got, want, rtol=2.0**-7, atol=1e-30)
+  lib = _lib.load()
+  for bad in (0.0, -0.1, 1.5):
+    assert lib.cg_lrelu_mix(H.p(out), H.p(out), H.p(out), H.p(out), B, n,
+                            ctypes.c_float(bad), H.stream()) != 0
+  assert lib.cg_lrelu_mix(H.p(out), H.p(out), H.p(out), H.p(out), B, 12,
+                          ctypes.c_float(0.2), H.stream()) != 0
+
+
 def test_wgan_gp_elementwise_kernels():
   rng = np.random.RandomState(13)
   B, L, C = 4, 32, 102

@@ -732,3 +732,71 @@ def test_batch_norm_generator(layer_norm, fixed_tiles):
                              atol=3e-2)
   v = gan2.validate(real)
   assert np.isfinite([float(v[1]), float(v[2]), float(v[3])]).all()
+
+
+@pytest.mark.parametrize('name', ['tiny', 'mid', 'odd_c', 'long', 'b1'])
+def test_first_critic_layer_on_the_interpolate_comes_from_the_other_two_segments(
+    name, monkeypatch):
+  """Round 5 (nets._L1_LINEAR; at batches of >= 16 384 layer-1 rows, forced here):
+  the critic's first Conv1D on x^ = a real + (1 - a) fake (wgan_gp.py:41-47 ->
+  calciumgan.py:159-166) is not convolved -- a convolution is linear, so its
+  pre-activation is a y_real + (1 - a) y_fake, taken from the stored activations of
+  the real and fake segments (cg_lrelu_mix).
+    * against the oracle's statement of exactly that (layer1_mix_pre on bf16-rounded
+      operands): >= 99.5 % of the activations identical, none further than one
+      bf16 ulp (the convolutions' f32 sums differ in order only);
+    * against the same plan convolving x^ (mix=None): the real / fake segments are
+      untouched bit for bit; on the x^ segment the two differ by storage rounding
+      (x^ rounded to bf16 on one side, y_real / y_fake on the other: <= 2^-7 of
+      |y_real| + |y_fake| + 2^-5 of the layer's rms per element, 1e-2 in relative
+      L2), and so do the critic's outputs (<= 0.1 of their spread: these toy
+      critics amplify one rounding to percents, tools/probe/critic_noise.py)."""
+  from calciumgan_amd import _lib, nets
+  monkeypatch.setattr(nets, '_L1_LINEAR_MIN_ROWS', 0)
+  hp, gen, dis, gan, real, B = _build(name)
+  L, C = real.shape[1], real.shape[2]
+  st = gan._get_state(B)
+  plan, ws = st['critic'], st['dws']
+  assert plan.mixes_layer1
+  dev = gan.device
+  rng = np.random.RandomState(5)
+  lay = dis.net.layers[0]
+  fake = rng.uniform(0, 1, (B, L, C)).astype(np.float32)
+  mix = rng.uniform(0, 1, B).astype(np.float32)
+  real_d, fake_d = torch.tensor(real, device=dev), torch.tensor(fake, device=dev)
+  alpha = torch.tensor(mix, device=dev)
+  s = nets._stream()
+  _lib.call('cg_interp_pack', nets._p(real_d), nets._p(fake_d), nets._p(alpha),
+            nets._p(plan.x0), B, lay.lin, lay.cin, lay.cin, lay.cin, lay.cinp, 1, s)
+  m = max(1, int(hp.m))
+  plan.shifts.copy_(torch.tensor(rng.randint(-m, m + 1, (4, 3)).astype(np.int32)))
+  plan.forward(mix=None)
+  torch.cuda.synchronize()
+  a_conv, d_conv = ws.act[1][:3 * B].float().cpu(), ws.d_out[:3 * B].cpu().clone()
+  ws.act[1].zero_()
+  plan.forward(mix=alpha)
+  torch.cuda.synchronize()
+  a_mix, d_mix = ws.act[1][:3 * B].float().cpu(), ws.d_out[:3 * B].cpu().clone()
+  # the oracle's statement of the mix
+  dw = [torch.tensor(w) for w in dis.get_weights()]
+  pre = O.layer1_mix_pre(dw, torch.tensor(real), torch.tensor(fake),
+                         torch.tensor(mix), hp, O.bf16_round, O.bf16_round)
+  want = O.bf16_round(O.activation_fn(getattr(hp, 'activation', 'leakyrelu'))(pre))
+  got = a_mix[2 * B:, :, :lay.cout]
+  assert float((got == want).float().mean()) >= 0.995
+  assert bool(((got - want).abs() <= 2.0**-7 * want.abs() + 1e-30).all())
+  assert float(a_mix[2 * B:, :, lay.cout:].abs().max() if lay.coutp > lay.cout
+               else 0.0) == 0.0
+  # the plan convolving x^
+  assert torch.equal(a_conv[:2 * B], a_mix[:2 * B])
+  assert torch.equal(d_conv[:2 * B], d_mix[:2 * B])
+  slope = dis.net.alpha
+  inv = lambda h: torch.where(h > 0, h, h / slope)
+  rms = a_conv[2 * B:].pow(2).mean().sqrt()
+  bound = 2.0**-7 * (inv(a_conv[:B]).abs() + inv(a_conv[B:2 * B]).abs()) + 2.0**-5 * rms
+  diff = (a_mix[2 * B:] - a_conv[2 * B:]).abs()
+  assert bool((diff <= bound).all()), float((diff - bound).max())
+  assert _rel(a_mix[2 * B:].numpy(), a_conv[2 * B:].numpy()) <= 1e-2
+  spread = float(d_conv.std())
+  np.testing.assert_allclose(d_mix[2 * B:].numpy(), d_conv[2 * B:].numpy(),
+                             atol=0.1 * spread)
