@@ -19,7 +19,7 @@ cp gpurun_out/swconv_traffic_by_geometry.txt gpurun_out/r05_swconv_traffic_by_ge
 {
   echo "Same-box A/Bs of round 5's switches (tools/ab_env.sh: bench.py --steps 40 per arm, two rounds, static tiles; the final losses are printed"
   echo "beside every rate -- arms whose arithmetic is the same end on the same bits)"
-  AB_STEPS=40 bash tools/ab_env.sh 2 "default:X=1" "wgrad_halves:CALCIUMGAN_WGRAD_FLEX=0" "pass_order_r4:CALCIUMGAN_SWP_CHUNK_INNER=0" "interp_separate:CALCIUMGAN_FUSE_INTERP=0" "all_three_r4:CALCIUMGAN_WGRAD_FLEX=0 CALCIUMGAN_SWP_CHUNK_INNER=0 CALCIUMGAN_FUSE_INTERP=0"
+  AB_STEPS=40 bash tools/ab_env.sh 2 "default:X=1" "wgrad_halves:CALCIUMGAN_WGRAD_FLEX=0" "pass_order_r4:CALCIUMGAN_SWP_CHUNK_INNER=0" "interp_separate:CALCIUMGAN_FUSE_INTERP=0" "l1_convolved:CALCIUMGAN_L1_LINEAR=0" "all_four_r4:CALCIUMGAN_WGRAD_FLEX=0 CALCIUMGAN_SWP_CHUNK_INNER=0 CALCIUMGAN_FUSE_INTERP=0 CALCIUMGAN_L1_LINEAR=0"
 } > gpurun_out/r05_ab.txt 2>&1
 cat gpurun_out/r05_ab.txt
 bash tools/bench_20_vs_400.sh > gpurun_out/r05_b20.log 2>&1; cp gpurun_out/bench_20_vs_400.txt gpurun_out/r05_bench_20_vs_400.txt; tail -8 gpurun_out/r05_bench_20_vs_400.txt | cut -c1-200
