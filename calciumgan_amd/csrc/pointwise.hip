@@ -966,7 +966,9 @@ __global__ __launch_bounds__(kThreads) void interp_pack_kernel(
   const long long row = idx / per_row;  // b*L + t
   const int c = (int)(idx - row * per_row) * 8;
   const int b = (int)(row / L);
-  const float al = alpha[b];
+  // (alpha == nullptr: [real | fake] only -- the caller takes layer 1 of x^ from
+  // the layer's outputs on the other two segments, cg_lrelu_mix)
+  const float al = alpha ? alpha[b] : 0.f;
   float r[8], f[8], x[8];
   // (the 8-channel group base c is a multiple of 8, so the loads are aligned
   // whenever the pitch is)
@@ -977,7 +979,7 @@ __global__ __launch_bounds__(kThreads) void interp_pack_kernel(
   const long long seg = (long long)B * L * Cp;
   if (write_real) store8(x0 + row * Cp + c, r);
   store8(x0 + seg + row * Cp + c, f);
-  store8(x0 + 2 * seg + row * Cp + c, x);
+  if (alpha) store8(x0 + 2 * seg + row * Cp + c, x);
 }
 
 __global__ __launch_bounds__(kThreads) void cast_pad_kernel(

@@ -208,7 +208,9 @@ class WGAN_GP(GAN):
     if not packed:  # (packed: plan.x0 already holds [real | fake | x^])
       if fake is None:
         fake = st['gws'].forward(z, keep=False, training=training)
-      _lib.call('cg_interp_pack', nets._p(real), nets._p(fake), nets._p(alpha),
+      # (a plan that mixes layer 1 of x^ never reads x^: [real | fake] only)
+      _lib.call('cg_interp_pack', nets._p(real), nets._p(fake),
+                nets._p(None if plan.mixes_layer1 else alpha),
                 nets._p(plan.x0), B, lay.lin, lay.cin, lay.cin,
                 self.generator.net.Cf, lay.cinp, 0 if real_cached else 1, s)
     plan.forward(seed_backward=True,

@@ -476,7 +476,8 @@ int cg_unshuffle_mask(const void* e /*bf16 [nB][w][Cp]*/, const void* h,
  * ------------------------------------------------------------------------- */
 /* x0[0:B]=bf16(real), x0[B:2B]=bf16(fake), x0[2B:3B]=bf16(alpha*real+(1-alpha)*fake)
  * (wgan_gp.py:38-41); real f32 [B][L][Cr], fake f32 [B][L][Cf] (row pitches,
- * C valid channels), x0 bf16 [3B][L][Cp]. */
+ * C valid channels), x0 bf16 [3B][L][Cp].  alpha == NULL (ABI 19): the third
+ * segment is left untouched (see cg_lrelu_mix). */
 int cg_interp_pack(const float* real, const float* fake, const float* alpha,
                    void* x0, int B, int L, int C, int Cr, int Cf, int Cp,
                    int write_real /* 0: x0[0:B] already holds bf16(real) */,

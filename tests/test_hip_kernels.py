@@ -692,6 +692,23 @@ def test_dense_rows_interp_equals_dense_rows_then_interp_pack(n, B, L, Ci, C, ep
   for k in range(n):
     assert float(ref[k].float().abs().max()) > 0
     assert torch.equal(ref[k].view(torch.int16), got[k].view(torch.int16)), k
+  # alpha == NULL (callers that take layer 1 of x^ from the other two segments,
+  # cg_lrelu_mix): [real | fake_k] as above, the third segment untouched -- by the
+  # fused launch and by cg_interp_pack alike
+  got2 = [torch.full((3 * B, L, cp), 9.0, dtype=BF16, device=H.DEV) for _ in range(n)]
+  ptrs2 = (ctypes.c_void_p * n)(*[t.data_ptr() for t in got2])
+  _lib.call('cg_dense_rows_interp', H.p(hd), H.p(op.buf), H.p(bd), H.p(real),
+            None, ptrs2, n, B, L, cip, C, C, cp, epi, H.stream())
+  x2 = torch.full((3 * B, L, cp), 9.0, dtype=BF16, device=H.DEV)
+  _lib.call('cg_interp_pack', H.p(real), H.p(fake), None, H.p(x2), B, L, C, C, cf,
+            cp, 1, H.stream())
+  H.sync()
+  for k in range(n):
+    assert torch.equal(got2[k][:2 * B].view(torch.int16),
+                       got[k][:2 * B].view(torch.int16)), k
+    assert bool((got2[k][2 * B:].float() == 9.0).all()), k
+  assert torch.equal(x2[:2 * B].view(torch.int16), ref[0][:2 * B].view(torch.int16))
+  assert bool((x2[2 * B:].float() == 9.0).all())
 
 
 @pytest.mark.parametrize('rows,Ci,Co,epi', [(1000, 512, 512, 3), (77, 256, 200, 0),

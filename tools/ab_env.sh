@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B on one box, one tile table: bench.py under several environments in turn.
 #   tools/ab_env.sh ROUNDS "label1:VAR=VAL VAR2=VAL" "label2:..." ...
+# AB_ARGS: further bench.py arguments (another workload), AB_STEPS: timed steps.
 # (the losses are printed beside the rates: an arm whose data went NaN runs at a
 # higher clock -- round 4's first "15 % faster" epilogue was one)
 # The first process tunes the tiles and saves its table; every timed run loads it
@@ -9,13 +10,13 @@
 ROUNDS=$1; shift
 export CALCIUMGAN_TILE_CACHE=${AB_TILES:-/tmp/cg_ab_tiles.json}
 if [ ! -f "$CALCIUMGAN_TILE_CACHE" ]; then
-  python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_kernel_timing > /dev/null 2>&1 || exit 1
+  python3 bench.py $AB_ARGS --steps 2 --warmup 1 --no_cpu_baseline --no_kernel_timing > /dev/null 2>&1 || exit 1
 fi
 export CALCIUMGAN_AUTOTUNE=0
 for r in $(seq 1 $ROUNDS); do
   for arm in "$@"; do
     label=${arm%%:*}; envs=${arm#*:}
-    env $envs python3 bench.py --steps ${AB_STEPS:-40} --warmup 3 --no_cpu_baseline 2>/dev/null | python3 -c "
+    env $envs python3 bench.py $AB_ARGS --steps ${AB_STEPS:-40} --warmup 3 --no_cpu_baseline 2>/dev/null | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=d['roofline']
