@@ -92,6 +92,39 @@ def test_every_documented_switch_is_a_working_configuration(knob):
   np.testing.assert_allclose(fb[3:], fa[3:], rtol=0.1, atol=0.02)
 
 
+@pytest.mark.parametrize('knob', ['', 'CALCIUMGAN_BATCH_G=0',
+                                  'CALCIUMGAN_SPLIT_SEGMENTS=1',
+                                  'CALCIUMGAN_FUSE_INTERP=0', 'CALCIUMGAN_GRAPH=0',
+                                  'CALCIUMGAN_FOLD_SCALE=0'])
+def test_layer1_mix_under_every_schedule(knob):
+  """The critic's first layer on x^ mixed from its outputs on real and fake
+  (round 5) applies from 16 384 layer-1 rows per segment, so the switch tests above
+  (batch 4) run the convolving plan.  Here the mix is forced at that shape
+  (CALCIUMGAN_L1_LINEAR_MIN_ROWS=0) under every schedule that feeds it differently:
+  the batched generator pass, one pass per update, the data-parallel segments, the
+  separate interpolate + pack launches (which no longer write x^), eager launches,
+  v formed by its own pass.  Against the convolving default: the first train()
+  within rounding (and z-order noise), three calls finite; the separate
+  interpolate + pack launches end on the same bits as the forced default."""
+  import numpy as np
+  shape = (2048, 102, 16, 4)
+  force = {'CALCIUMGAN_L1_LINEAR_MIN_ROWS': '0'}
+  a = _run(3, shape)
+  extra = dict(force)
+  if knob:
+    name, value = knob.split('=')
+    extra[name] = value
+  b = _run(3, shape, extra)
+  assert np.isfinite(b['last']).all(), b
+  fa, fb = np.asarray(a['first']), np.asarray(b['first'])
+  assert (np.abs(fb[:3] - fa[:3]) <= 0.25 * np.abs(fa[:3]) + 1.0).all(), (fa, fb)
+  np.testing.assert_allclose(fb[3:], fa[3:], rtol=0.1, atol=0.02)
+  if knob == 'CALCIUMGAN_FUSE_INTERP=0':
+    c = _run(3, shape, force)
+    assert b['outputs'] == c['outputs'], (b['last'], c['last'])
+    assert b['weights'] == c['weights']
+
+
 def test_fused_penalty_launch_equals_the_three_launches_bit_for_bit():
   """cg_gp_loss_scale (slot sums + gp / coef / loss + v's scale) against
   rowsumsq_finish -> cg_gp_critic_loss -> cg_scale_rows (CALCIUMGAN_FUSE_GP=0):
