@@ -10,7 +10,9 @@ from ... import parallel
 from .optimizer import Optimizer
 from .registry import register
 
-_SEED = 1234  # main.py:11-12
+# main.py:11-12 (CALCIUMGAN_SEED: another draw of the noise / interpolation /
+# shift streams, for seed-to-seed comparisons -- tools/e2e_seeds.sh)
+_SEED = int(__import__('os').environ.get('CALCIUMGAN_SEED', '1234'))
 
 
 @register('gan')

@@ -81,6 +81,15 @@ def main(hparams):
         '{mape:.02f}%'.format(**r['firing_rate']))
   print('\ncovariance\n\tMAE\t{mae:.02f}\n\tMSE\t{mse:.02f}\n\tMAPE\t'
         '{mape:.02f}%'.format(**r['covariance']))
+  path = os.environ.get('CALCIUMGAN_METRICS_JSON')
+  if path:  # (development: the same numbers at full precision, plus the means)
+    import json
+    r['population'] = dict(real_rate=float(np.mean(real_fr)),
+                           fake_rate=float(np.mean(fake_fr)),
+                           real_cov=float(np.mean(real_cov)),
+                           fake_cov=float(np.mean(fake_cov)))
+    with open(path, 'w') as f:
+      json.dump(r, f)
   return r
 
 
