@@ -307,6 +307,15 @@ struct DenseWideArgs {
   void* y;              // f32 or bf16 [rows][Cy]
   long long rows;
   int Cx, N, Cy, epilogue, out_act, panels;
+  // interpolation epilogue (cg_dense_rows_interp at pitches beyond 128; real ==
+  // nullptr: plain output into y).  Rows are [n_upd][seg_rows] (seg_rows = B * L, a
+  // multiple of 32: a wave's 32-row block lies in one update); update k's rows go,
+  // in bf16, to x0[k] = [real | fake_k | x^_k] (alpha == nullptr: no x^), pitch Cy
+  const float* real;    // f32 [seg_rows][Cr]
+  const float* alpha;   // f32 [n_upd * B] or null
+  uint16_t* x0[kMaxInterp];
+  long long seg_rows;
+  int n_upd, L, Cr;
 };
 
 // (K = 128: the panel is 34 KB and the fragment sets 230 registers -- two
@@ -415,6 +424,14 @@ __global__ __launch_bounds__(kWideThreads, KSTEPS <= 4 ? 2 : 1) void dense_rows_
       mm(wb, ks + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // (interpolation epilogue: the block's update and its input buffer, uniform)
+    const bool interp = a.n_upd > 0;
+    long long kupd = 0;
+    uint16_t* x0k = nullptr;
+    if (interp) {
+      kupd = (b * 32) / a.seg_rows;
+      x0k = a.x0[kupd < a.n_upd ? kupd : 0];
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const long long m = b * 32 + h * 16 + r16;
@@ -437,7 +454,38 @@ __global__ __launch_bounds__(kWideThreads, KSTEPS <= 4 ? 2 : 1) void dense_rows_
             const float sg = 1.f / (1.f + __expf(-t));
             v[e] = (n + e < a.N) ? (sig ? sg : t) : 0.f;  // padding stays zero
           }
-          if (a.out_act) {
+          if (interp) {
+            // fake_k of the row's update in bf16, straight into its segment of x0[k]
+            // -- stores only: with one wave per SIMD nothing would hide a load here
+            // (the real segments come from real_bcast_kernel).  With `real` (a
+            // caller that wants x^ = a real + (1 - a) fake, wgan_gp.py:38-41) the
+            // row's real values are loaded and all three segments written, as
+            // cg_interp_pack forms them from the f32 values.
+            const long long rem = m - kupd * a.seg_rows;
+            uint16_t* q = x0k + rem * a.Cy + n;
+            const long long seg = a.seg_rows * a.Cy;
+            *reinterpret_cast<uint4*>(q + seg) =
+                make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]),
+                           pack2act(v[4], v[5]), pack2act(v[6], v[7]));
+            if (a.real) {
+              const float* rp = a.real + rem * a.Cr + n;
+              float rv[8], xh[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) rv[e] = (n + e < a.N) ? rp[e] : 0.f;
+              *reinterpret_cast<uint4*>(q) =
+                  make_uint4(pack2act(rv[0], rv[1]), pack2act(rv[2], rv[3]),
+                             pack2act(rv[4], rv[5]), pack2act(rv[6], rv[7]));
+              if (a.alpha) {
+                const float al =
+                    a.alpha[kupd * (a.seg_rows / a.L) + (int)(rem / a.L)];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xh[e] = al * rv[e] + (1.f - al) * v[e];
+                *reinterpret_cast<uint4*>(q + 2 * seg) =
+                    make_uint4(pack2act(xh[0], xh[1]), pack2act(xh[2], xh[3]),
+                               pack2act(xh[4], xh[5]), pack2act(xh[6], xh[7]));
+              }
+            }
+          } else if (a.out_act) {
             *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.y) +
                                       m * a.Cy + n) =
                 make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]),
@@ -482,9 +530,17 @@ int launch_dense_wide(const DenseWideArgs& a, hipStream_t s) {
   CG_LAUNCH_CHECK();
 }
 
+struct DenseWideInterp {  // the interpolation epilogue's arguments (or null)
+  const float* real;
+  const float* alpha;
+  void* const* x0;
+  int n, B, L, Cr;
+};
+
 int dense_rows_wide(const void* x, const void* w, const float* bias, void* y,
                     long long rows, int Cx, int N, int Cy, int epilogue,
-                    int out_act, hipStream_t s) {
+                    int out_act, hipStream_t s,
+                    const DenseWideInterp* ip = nullptr) {
   if (Cx % 32 || N < 1 || Cy < N || Cy % 8) return CG_EINVAL;
   DenseWideArgs a;
   a.x = reinterpret_cast<const uint16_t*>(x);
@@ -493,6 +549,21 @@ int dense_rows_wide(const void* x, const void* w, const float* bias, void* y,
   a.y = y;
   a.rows = rows;
   a.Cx = Cx; a.N = N; a.Cy = Cy; a.epilogue = epilogue; a.out_act = out_act;
+  a.real = nullptr; a.alpha = nullptr; a.seg_rows = 1; a.n_upd = 0; a.L = 1; a.Cr = 0;
+  for (int k = 0; k < kMaxInterp; ++k) a.x0[k] = nullptr;
+  if (ip) {
+    const long long seg = (long long)ip->B * ip->L;
+    // (real == nullptr: the fake segments only -- then there is no x^ either)
+    if (!ip->x0 || ip->n < 1 || ip->n > kMaxInterp || seg % 32 ||
+        rows != seg * ip->n || (ip->real && ip->Cr < N) || (!ip->real && ip->alpha))
+      return CG_EINVAL;
+    a.real = ip->real; a.alpha = ip->alpha; a.seg_rows = seg;
+    a.n_upd = ip->n; a.L = ip->L; a.Cr = ip->Cr;
+    for (int k = 0; k < ip->n; ++k) {
+      a.x0[k] = reinterpret_cast<uint16_t*>(ip->x0[k]);
+      if (!a.x0[k]) return CG_EINVAL;
+    }
+  }
   // (the packed operand is padded to 128 columns: whole panels are readable)
   a.panels = (N + kWideCols - 1) / kWideCols;
   if (a.panels > 32) return CG_EINVAL;
@@ -710,6 +781,37 @@ extern "C" int cg_dense_rows(const void* x, const void* w, const float* bias,
   CG_LAUNCH_CHECK();
 }
 
+// real (f32 [rows][Cr]) -> the bf16 real segment of every update's input buffer:
+// one read, n writes (the LDS-panel form of cg_dense_rows_interp without x^)
+struct RealBcastArgs {
+  const float* real;
+  uint16_t* x0[kMaxInterp];
+  long long total8;
+  int n, N, Cr, Cp;
+};
+__global__ __launch_bounds__(256) void real_bcast_kernel(RealBcastArgs a) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.total8) return;
+  const int per_row = a.Cp / 8;
+  const long long row = idx / per_row;
+  const int c = (int)(idx - row * per_row) * 8;
+  const float* rp = a.real + row * a.Cr + c;
+  float v[8];
+  if ((a.Cr & 3) == 0 && c + 8 <= a.N) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(rp);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (c + e < a.N) ? rp[e] : 0.f;
+  }
+  const uint4 o = make_uint4(pack2act(v[0], v[1]), pack2act(v[2], v[3]),
+                             pack2act(v[4], v[5]), pack2act(v[6], v[7]));
+  for (int k = 0; k < a.n; ++k)
+    *reinterpret_cast<uint4*>(a.x0[k] + row * a.Cp + c) = o;
+}
+
 // cg_dense_rows for the fake batches of all n critic updates of a step, fused
 // with cg_interp_pack: x0[k] (bf16 [3 B][L][Cp]) receives [real | fake_k | x^_k]
 // (alpha == NULL: [real | fake_k | untouched]).
@@ -722,6 +824,29 @@ extern "C" int cg_dense_rows_interp(const void* x, const void* w, const float* b
       L % 16)
     return CG_EINVAL;
   if (epilogue != CG_EPI_NONE && epilogue != CG_EPI_SIGMOID) return CG_EINVAL;
+  if (Cx > 128 || N > 128) {
+    // the LDS-panel form (BASELINE configs[4]: 512 -> 512): the same epilogue
+    // behind its accumulators; B * L must be a multiple of 32
+    if (Cp < N || Cp % 8) return CG_EINVAL;
+    // without x^ the Dense only STORES (its fake segments) and one more launch
+    // reads `real` once for the n real segments; with x^ its epilogue loads the
+    // rows of `real` itself (exposed latency at one wave per SIMD: no faster than
+    // the separate launches, kept for callers that convolve x^)
+    const DenseWideInterp ip = {alpha ? real : nullptr, alpha, x0, n, B, L, Cr};
+    const int rc = dense_rows_wide(x, w, bias, nullptr, (long long)n * B * L, Cx, N,
+                                   Cp, epilogue, 0, (hipStream_t)stream, &ip);
+    if (rc != 0 || alpha) return rc;
+    RealBcastArgs ra;
+    ra.real = real;
+    for (int k = 0; k < kMaxInterp; ++k)
+      ra.x0[k] = k < n ? reinterpret_cast<uint16_t*>(x0[k]) : nullptr;
+    ra.total8 = (long long)B * L * (Cp / 8);
+    ra.n = n; ra.N = N; ra.Cr = Cr; ra.Cp = Cp;
+    hipLaunchKernelGGL(real_bcast_kernel,
+                       dim3((unsigned)((ra.total8 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, ra);
+    CG_LAUNCH_CHECK();
+  }
   if (Cx % 32 || Cx < 32 || Cx > 128 || N < 1 || N > 128 || Cp != 128 || Cr < N)
     return CG_EINVAL;
   DenseInterpArgs a;

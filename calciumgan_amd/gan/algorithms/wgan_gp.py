@@ -145,9 +145,9 @@ class WGAN_GP(GAN):
     return pl
 
   def _can_fuse_interp(self, B, n, gws=None):
-    """cg_dense_rows_interp applies: the register form of the output Dense (pitch
-    128), n <= 8 updates.  gws: the generator workspace of the pass (default: the
-    forward-only one over n * B samples)."""
+    """cg_dense_rows_interp applies: the streaming output Dense (register form at
+    pitch 128, LDS-panel form beyond), n <= 8 updates.  gws: the generator
+    workspace of the pass (default: the forward-only one over n * B samples)."""
     if not _FUSE_INTERP:
       return False
     if gws is None:

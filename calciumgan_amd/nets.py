@@ -1304,11 +1304,17 @@ class _GenWorkspace(object):
                                   w0 * nd, 1, 1, 0, nd, w0 * nd, slot='in')
 
   def can_interp(self, n):
-    """Whether forward(interp=...) exists for this model: the register form of
-    the streaming output Dense, a 128-channel pitch, whole 16-row blocks."""
+    """Whether forward(interp=...) exists for this model: the streaming output
+    Dense -- its register form at a 128-channel pitch (whole 16-row blocks), its
+    LDS-panel form beyond (32-row blocks inside one update: B * L % 32 == 0)."""
     net = self.net
-    return bool(net.streaming_out and net.Cp == 128 and net.L % 16 == 0 and
-                1 <= n <= 8 and self.B % n == 0)
+    if not (net.streaming_out and net.L % 16 == 0 and 1 <= n <= 8 and
+            self.B % n == 0):
+      return False
+    if net.Cp == 128:
+      return True
+    return (net.Cp // 32 in (4, 8, 12, 16) and
+            ((self.B // n) * net.L) % 32 == 0)
 
   def forward(self, z_f32, keep=True, training=True, interp=None):
     """z (B, nd) f32 device -> self.fake (B, L, Cf) f32 (first C channels).

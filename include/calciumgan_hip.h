@@ -232,10 +232,14 @@ int cg_swconv_check(const cg_conv_desc* d);
 int cg_dense_rows(const void* x, const void* w, const float* bias, float* y,
                   long long rows, int Cx, int N, int Cy, int epilogue,
                   void* stream);
-/* cg_dense_rows (register form: Cx in {32, 64, 96, 128}, N <= 128) for the fake
- * batches of ALL n critic updates of one train() -- x bf16 [n * B * L][Cx], the
- * generator's last hidden layer over n * B samples -- fused with cg_interp_pack:
- * x0[k] (bf16 [3 B][L][Cp], Cp = 128) receives [real | fake_k | x^_k], x^ =
+/* cg_dense_rows for the fake batches of ALL n critic updates of one train() -- x
+ * bf16 [n * B * L][Cx], the generator's last hidden layer over n * B samples --
+ * fused with cg_interp_pack.  Register form: Cx in {32, 64, 96, 128}, N <= 128, Cp =
+ * 128.  LDS-panel form (ABI 19; BASELINE configs[4]): Cx in {128, 256, 384, 512}
+ * with Cx > 128 or N > 128, Cp >= N a multiple of 8, B * L % 32 == 0; without x^
+ * (alpha == NULL) the Dense only stores its fake segments and a second launch
+ * reads `real` once for the n real segments.
+ * x0[k] (bf16 [3 B][L][Cp]) receives [real | fake_k | x^_k], x^ =
  * alpha[k * B + b] * real + (1 - alpha) * fake (wgan_gp.py:38-41, interpolation
  * in f32 on the f32 Dense output as the reference does).  The f32 fake batch
  * never reaches HBM and `real` (f32 [B][L][Cr]) is read once.  L % 16 == 0,

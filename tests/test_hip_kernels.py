@@ -656,7 +656,12 @@ def test_dense_rows_streaming(rows, Ci, Co, epi):
 @pytest.mark.parametrize('n,B,L,Ci,C,epi', [(5, 3, 64, 128, 102, 3),
                                             (2, 70, 16, 64, 102, 0),
                                             (1, 2, 2048, 128, 128, 3),
-                                            (8, 1, 32, 96, 97, 3)])
+                                            (8, 1, 32, 96, 97, 3),
+                                            # the LDS-panel form (configs[4]: 512 -> 512)
+                                            (2, 3, 32, 512, 512, 3),
+                                            (3, 1, 64, 256, 200, 0),
+                                            (1, 2, 16, 128, 130, 3),
+                                            (5, 2, 80, 384, 300, 3)])
 def test_dense_rows_interp_equals_dense_rows_then_interp_pack(n, B, L, Ci, C, epi):
   """cg_dense_rows_interp -- the generator's output Dense (+ sigmoid,
   calciumgan.py:96-101) over the fake batches of all n critic updates of a step,
@@ -666,7 +671,7 @@ def test_dense_rows_interp_equals_dense_rows_then_interp_pack(n, B, L, Ci, C, ep
   [real | fake_k | x^_k] equal."""
   rng = np.random.RandomState(33)
   cip = geo.pitch(Ci)
-  cp = 128
+  cp = 128 if (Ci <= 128 and C <= 128) else geo.pitch(C)
   cf = (C + 7) // 8 * 8
   h = torch.tensor(rng.randn(1, n * B * L, Ci).astype(np.float32))
   W = torch.tensor(rng.randn(Ci, C).astype(np.float32) * 0.2)
