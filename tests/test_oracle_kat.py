@@ -251,3 +251,21 @@ def test_dynamic_loss_scale_state_machine():
   gan.train(real, O.draw_randomness(hp, 2, 0))
   assert gan.dis_steps == hp.n_critic and gan.gen_steps == 1
   assert gan.dis_scale.good_steps == hp.n_critic
+
+
+def test_gram_operator_identities_of_the_penalty_first_layer():
+  """DESIGN section 9's costed lead, pinned before anybody builds it: the input
+  gradient g of the critic's first Conv1D enters the step only through ||g||^2, the
+  tangent's first layer conv(c g) and layer 1's weight gradient -- all three are
+  functions of delta_1 through G = W^T W (23 lags, Co x Co; truncated kernels in the
+  first / last six rows of a sample).  float64, the oracle's Conv1D as ground truth
+  (tools/probe/gram_layer1.py)."""
+  import importlib.util
+  import os
+  path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                      'tools', 'probe', 'gram_layer1.py')
+  spec = importlib.util.spec_from_file_location('gram_layer1', path)
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  assert mod.check(T=20, ci=5, co=4, seed=0) < 1.0
+  mod.check(T=13, ci=3, co=6, seed=1)
